@@ -1,0 +1,111 @@
+"""Host-side camera: the two 4x4 fp32 matrices the rasterizer consumes.
+
+Mirrors the attribute surface of the reference camera
+(``Utils/Camera.py:10-28``: ``width``, ``height``, ``fx``, ``fy``, ``cx``,
+``cy``, ``transform.position``, ``world2model_matrix``, ``projection_matrix``)
+so that the renderer accepts either this class or the reference's own
+``Camera`` object.  The matrices are built on the host exactly the way the
+reference builds them:
+
+* world->model = inv(T @ R @ S) with T, R, S assembled in float32 numpy
+  (``Utils/Transform.py:28-38,73-84,109-138``),
+* OpenGL-style projection computed in float64 and cast to float32
+  (``Utils/Camera.py:48-64``), near 0.1, far 100.
+
+They are 32 floats per view and stay on the host; the kernels receive them
+as launch constants.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+class _Pose:
+    """Position + unit quaternion (w, x, y, z) + scale, like ``Utils/Transform.py:6-25``."""
+
+    def __init__(self, position, rotation=None, scale=None):
+        self.position = np.asarray(position)
+        self.rotation = np.array([1, 0, 0, 0]) if rotation is None else np.asarray(rotation)
+        self.scale = np.array([1, 1, 1]) if scale is None else np.asarray(scale)
+        if self.rotation.shape[0] != 4:
+            raise ValueError(f"Rotation should have shape 4 but get {self.rotation.shape[0]}")
+        if self.scale.shape[0] != 3:
+            raise ValueError(f"Scale should have shape 3 but get {self.scale.shape[0]}")
+
+    def model2world(self) -> np.ndarray:
+        w, x, y, z = (self.rotation[i] for i in range(4))
+        rot = np.array(
+            [
+                [2 * (w * w + x * x) - 1, 2 * (x * y - w * z), 2 * (x * z + w * y), 0],
+                [2 * (x * y + w * z), 2 * (w * w + y * y) - 1, 2 * (y * z - w * x), 0],
+                [2 * (x * z - w * y), 2 * (y * z + w * x), 2 * (w * w + z * z) - 1, 0],
+                [0, 0, 0, 1],
+            ],
+            dtype=np.float32,
+        )
+        px, py, pz = (self.position[i] for i in range(3))
+        trans = np.array([[1, 0, 0, px], [0, 1, 0, py], [0, 0, 1, pz], [0, 0, 0, 1]], dtype=np.float32)
+        sx, sy, sz = (self.scale[i] for i in range(3))
+        scl = np.array([[sx, 0, 0, 0], [0, sy, 0, 0], [0, 0, sz, 0], [0, 0, 0, 1]], dtype=np.float32)
+        return trans @ rot @ scl
+
+    def world2model(self) -> np.ndarray:
+        return np.linalg.inv(self.model2world())
+
+
+class Camera:
+    """Pinhole camera handed to ``GaussianRenderer.render``.
+
+    ``width`` is the slow image axis and ``height`` the fast one: the renderer
+    writes ``[width, height, 3]`` (``GaussianRenderer.py:84``).
+    """
+
+    def __init__(self, position, rotation, focal_length_x, focal_length_y,
+                 principal_point_x, principal_point_y, width, height, device=None):
+        self.transform = _Pose(position, rotation=rotation)
+        self.fx = focal_length_x
+        self.fy = focal_length_y
+        self.cx = principal_point_x
+        self.cy = principal_point_y
+        self.height = height
+        self.width = width
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = device
+        self.w2m_host = np.ascontiguousarray(self.transform.world2model(), dtype=np.float32)
+        self.proj_host = np.ascontiguousarray(self.get_projection_matrix(), dtype=np.float32)
+        self.world2model_matrix = torch.from_numpy(self.w2m_host).to(device=device, dtype=torch.float32)
+        self.projection_matrix = torch.from_numpy(self.proj_host).to(device=device, dtype=torch.float32)
+
+    def get_projection_matrix(self, near: float = 0.1, far: float = 100) -> np.ndarray:
+        fov_x = 2 * math.atan(self.width / (2 * self.fx))
+        fov_y = 2 * math.atan(self.height / (2 * self.fy))
+        top = near * math.tan(fov_y / 2)
+        bottom = -top
+        right = near * math.tan(fov_x / 2)
+        left = -right
+        return np.array(
+            [
+                [2 * near / (right - left), 0, 0, -near * (right + left) / (right - left)],
+                [0, 2 * near / (top - bottom), 0, -near * (top + bottom) / (top - bottom)],
+                [0, 0, -(far + near) / (far - near), 2 * far * near / (near - far)],
+                [0, 0, -1, 0],
+            ],
+            dtype=float,
+        )
+
+
+def camera_constants(cam):
+    """Return ``(w2m[16], proj[16], position[3])`` as contiguous float32 numpy
+    arrays from either this module's ``Camera`` or the reference's."""
+    if hasattr(cam, "w2m_host"):
+        w2m, proj = cam.w2m_host, cam.proj_host
+    else:
+        w2m = cam.world2model_matrix.detach().cpu().numpy()
+        proj = cam.projection_matrix.detach().cpu().numpy()
+    w2m = np.ascontiguousarray(w2m, dtype=np.float32).reshape(16)
+    proj = np.ascontiguousarray(proj, dtype=np.float32).reshape(16)
+    # GaussianRenderer.py:73 casts the camera position to float32 before the subtraction.
+    pos = np.ascontiguousarray(np.asarray(cam.transform.position), dtype=np.float32).reshape(3)
+    return w2m, proj, pos

@@ -1,0 +1,69 @@
+"""Generates tests/golden/*.npz by running the REFERENCE renderer on seeded scenes.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Each fixture holds the raw inputs, the camera constants, the cotangent used for the backward
+(loss = sum(img * cotangent)), and everything the reference produced: visibility mask, per-stage
+intermediates (compacted to the visible set, as the reference holds them), per-tile depth-sorted
+lists (stable order, original Gaussian indices), the image and the six gradients.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import gsplat_amd  # noqa: E402,F401
+from gsplat_amd.scenes import (adversarial_scene, all_culled_scene, orbit_scene,  # noqa: E402
+                               synthetic_scene)
+import ref_harness  # noqa: E402
+
+# name -> (scene factory, tile_length)
+CASES = {
+    "syn_n256_64x48_deg0_t16": (lambda: synthetic_scene(256, 64, 48, 0, seed=10), 16),
+    "syn_n256_64x48_deg1_t64": (lambda: synthetic_scene(256, 64, 48, 1, seed=11), 64),
+    "syn_n1024_128x96_deg2_t16": (lambda: synthetic_scene(1024, 128, 96, 2, seed=12), 16),
+    "syn_n2048_128x96_deg3_t64": (lambda: synthetic_scene(2048, 128, 96, 3, seed=13), 64),
+    "adv_n2048_128x96_deg2_t16": (lambda: adversarial_scene(2048, 128, 96, 2, seed=14), 16),
+    "adv_n1024_130x70_deg3_t64": (lambda: adversarial_scene(1024, 130, 70, 3, seed=15), 64),
+    "orbit_n512_100x100_deg3_t16": (lambda: orbit_scene(512, 100, 100, 3, view=1, n_views=8, seed=16), 16),
+    "syn_n512_64x48_deg3_t10": (lambda: synthetic_scene(512, 64, 48, 3, seed=17), 10),
+    "culled_n256_64x48_deg0_t16": (lambda: all_culled_scene(256, 64, 48, 0, seed=18), 16),
+}
+
+
+def main():
+    assert ref_harness.reference_available(), "needs /root/reference"
+    for name, (factory, tile) in CASES.items():
+        sc = factory()
+        cot = torch.rand(sc.width, sc.height, 3, generator=torch.Generator().manual_seed(1234),
+                         dtype=torch.float32).numpy()
+        out = ref_harness.run_reference(sc, tile, cot)
+        cam = sc.camera(device="cpu")
+        data = dict(
+            coords=sc.coords.numpy(), scale=sc.scale.numpy(), rotation=sc.rotation.numpy(),
+            opacity=sc.opacity.numpy(), sh=sc.sh.numpy(), sh_degree=np.int32(sc.sh_degree),
+            width=np.int32(sc.width), height=np.int32(sc.height), tile_length=np.int32(tile),
+            w2m=cam.w2m_host, proj=cam.proj_host,
+            cam_pos=np.asarray(sc.cam_position, dtype=np.float32), cotangent=cot,
+            visible=np.bool_(out["img"] is not None),
+        )
+        if out["img"] is not None:
+            for k, v in out.items():
+                data["ref_" + k] = v
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **data)
+        print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB"
+              + ("" if out["img"] is None else f", visible {int(out['mask'].sum())}/{sc.n}, "
+                 f"pairs {len(out['tile_lists'])}"))
+
+
+if __name__ == "__main__":
+    main()
