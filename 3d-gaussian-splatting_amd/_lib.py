@@ -1,0 +1,87 @@
+"""ctypes binding of ``libgsr.so`` (the C ABI declared in ``include/gsr.h``).
+
+The library is built in-tree by ``make -C csrc`` (hipcc, gfx950).  There is no CPU fallback:
+``load()`` raises when the shared object is missing, and every wrapper raises ``RuntimeError``
+with the library's message on a non-zero return code.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(CSRC, "libgsr.so")
+
+REC_FLOATS = 12
+PAIRGRAD_FLOATS = 12
+
+# Every symbol include/gsr.h declares.
+SYMBOLS = (
+    "gsr_last_error", "gsr_version", "gsr_preprocess_fwd", "gsr_preprocess_bwd",
+    "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
+    "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_lists_workspace_bytes", "gsr_bin_lists",
+    "gsr_composite_fwd", "gsr_composite_bwd",
+)
+
+
+class GsrView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("sh_degree", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("tile_length", C.c_int32), ("w2m", C.c_float * 16), ("proj", C.c_float * 16),
+                ("cam_pos", C.c_float * 3)]
+
+
+def make_view(n, sh_degree, width, height, tile_length, w2m, proj, cam_pos) -> GsrView:
+    v = GsrView()
+    v.n, v.sh_degree, v.width, v.height, v.tile_length = int(n), int(sh_degree), int(width), int(height), int(tile_length)
+    v.w2m[:] = [float(x) for x in w2m]
+    v.proj[:] = [float(x) for x in proj]
+    v.cam_pos[:] = [float(x) for x in cam_pos]
+    return v
+
+
+def build(force: bool = False) -> str:
+    """Compile libgsr.so for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built (run `make -C {CSRC}` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name in SYMBOLS:
+        if not hasattr(lib, name):
+            raise RuntimeError(f"{LIB_PATH} does not export {name}")
+    lib.gsr_last_error.restype = C.c_char_p
+    for name in ("gsr_sort_workspace_bytes", "gsr_scan_workspace_bytes", "gsr_bin_offsets_workspace_bytes",
+                 "gsr_bin_lists_workspace_bytes"):
+        getattr(lib, name).restype = C.c_size_t
+        getattr(lib, name).argtypes = [C.c_uint32]
+    vp = C.c_void_p
+    lib.gsr_preprocess_fwd.argtypes = [C.POINTER(GsrView)] + [vp] * 16
+    lib.gsr_preprocess_bwd.argtypes = [C.POINTER(GsrView)] + [vp] * 16 + [C.c_int, vp]
+    lib.gsr_sort_pairs.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
+    lib.gsr_exclusive_scan.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_offsets.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_lists.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_composite_fwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp]
+    lib.gsr_composite_bwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, C.c_uint32, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().gsr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed ({code}): {msg}")

@@ -1,0 +1,182 @@
+// Stage 2: depth order of the Gaussians, per-pair slots, per-tile lists.
+//
+// The reference builds, for every tile, a boolean membership mask over all visible Gaussians and
+// argsorts the members by NDC depth (Utils/Screen.py:58-62, GaussianRenderer.py:85-95).  Here the
+// same lists come out of one least-significant-digit radix sort of the composite key
+// (tile id, depth bits): the four depth digits are sorted once per Gaussian - they are equal for
+// all tiles a Gaussian touches - and the tile digits once per (tile, Gaussian) pair.  Both sorts
+// are stable and pairs are emitted in depth order, so ties in depth keep ascending Gaussian index.
+#include "gsr_common.hpp"
+
+namespace {
+
+__global__ void iota_kernel(uint32_t *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+__global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                                  uint32_t *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+
+__global__ void scatter_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                                   uint32_t *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[idx[i]] = src[i];
+}
+
+// One thread per Gaussian: write the tile id of each of its pairs into its slots.
+// Slot e of Gaussian g: e = slot_base[g] + (xi - x0) * ny + (yi - y0).
+__global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t *__restrict__ slot_base,
+                                                         const int32_t *__restrict__ bbox,
+                                                         const uint32_t *__restrict__ ntiles,
+                                                         uint32_t *__restrict__ tile_key,
+                                                         uint32_t *__restrict__ slot_id,
+                                                         uint32_t *__restrict__ owner, uint32_t num_pairs)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= v.n) return;
+    const uint32_t nt = ntiles[g];
+    if (nt == 0) return;
+    const int4 bb = reinterpret_cast<const int4 *>(bbox)[g];
+    int x0, x1, y0, y1;
+    gsr_tile_span(bb.x, bb.z, v.L, x0, x1);
+    gsr_tile_span(bb.y, bb.w, v.L, y0, y1);
+    uint32_t e = slot_base[g];
+    for (int xi = x0; xi <= x1; ++xi)
+        for (int yi = y0; yi <= y1; ++yi) {
+            if (e < num_pairs) {  // guards a stale num_pairs; never taken on consistent input
+                tile_key[e] = (uint32_t)(yi + v.nbh * xi);
+                slot_id[e] = e;
+                owner[e] = (uint32_t)g;
+            }
+            ++e;
+        }
+}
+
+// One thread per sorted position p: copy the owner's splat record into the stream, record where
+// slot e went, and mark tile boundaries.
+__global__ __launch_bounds__(256) void finalize_lists_kernel(
+    const uint32_t *__restrict__ sorted_tile, const uint32_t *__restrict__ sorted_slot,
+    const uint32_t *__restrict__ owner, const float *__restrict__ rec, uint32_t num_pairs, uint32_t T,
+    uint32_t *__restrict__ tile_offsets, uint32_t *__restrict__ pair_pos, uint32_t *__restrict__ sorted_gauss,
+    float *__restrict__ stream_rec)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= num_pairs) return;
+    const uint32_t e = sorted_slot[p];
+    const uint32_t g = owner[e];
+    pair_pos[e] = p;
+    sorted_gauss[p] = g;
+    const float4 *src = reinterpret_cast<const float4 *>(rec + (size_t)g * GSR_REC_FLOATS);
+    float4 *dst = reinterpret_cast<float4 *>(stream_rec + (size_t)p * GSR_REC_FLOATS);
+    float4 a = src[0], b = src[1], c = src[2];
+    dst[0] = a; dst[1] = b; dst[2] = c;
+    const uint32_t cur = sorted_tile[p];
+    const uint32_t first = p == 0 ? 0u : sorted_tile[p - 1] + 1u;
+    for (uint32_t t = first; t <= cur; ++t) tile_offsets[t] = p;  // tiles (prev, cur] start at p
+    if (p + 1 == num_pairs)
+        for (uint32_t t = cur + 1; t <= T; ++t) tile_offsets[t] = num_pairs;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline int bits_for(uint32_t count)
+{
+    int b = 0;
+    while (b < 32 && (1ull << b) < (unsigned long long)count) ++b;
+    return b;
+}
+
+}  // namespace
+
+extern "C" size_t gsr_bin_offsets_workspace_bytes(uint32_t n)
+{
+    const size_t arr = align256((size_t)(n ? n : 1) * sizeof(uint32_t));
+    return 3 * arr + gsr_sort_workspace_bytes(n) + gsr_scan_workspace_bytes(n);
+}
+
+extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uint32_t *order,
+                               uint32_t *slot_base, gsr_counters *counters, void *workspace,
+                               size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!workspace || workspace_bytes < gsr_bin_offsets_workspace_bytes(n)) {
+        gsr_set_error("gsr_bin_offsets: workspace too small");
+        return GSR_ERR_ARG;
+    }
+    if (!counters) { gsr_set_error("gsr_bin_offsets: null counters"); return GSR_ERR_ARG; }
+    if (n == 0) {
+        (void)hipMemsetAsync(&counters->num_pairs, 0, sizeof(uint32_t), st);
+        return GSR_OK;
+    }
+    if (!depth_key || !ntiles || !order || !slot_base) { gsr_set_error("gsr_bin_offsets: null pointer"); return GSR_ERR_ARG; }
+    const size_t arr = align256((size_t)n * sizeof(uint32_t));
+    char *ws = (char *)workspace;
+    uint32_t *ids = (uint32_t *)ws;               // 0..n-1, clobbered by the sort
+    uint32_t *keys_sorted = (uint32_t *)(ws + arr);
+    uint32_t *tmp = (uint32_t *)(ws + 2 * arr);   // ntiles in depth order, then their scan
+    void *sort_ws = ws + 3 * arr;
+    const size_t sort_bytes = gsr_sort_workspace_bytes(n);
+    void *scan_ws = (char *)sort_ws + sort_bytes;
+    const size_t scan_bytes = gsr_scan_workspace_bytes(n);
+    const dim3 grid(gsr_div_up(n, 256)), block(256);
+    hipLaunchKernelGGL(iota_kernel, grid, block, 0, st, ids, n);
+    if (int e = gsr_sort_pairs(depth_key, ids, keys_sorted, order, n, 0, 32, sort_ws, sort_bytes, stream)) return e;
+    hipLaunchKernelGGL(gather_u32_kernel, grid, block, 0, st, ntiles, order, tmp, n);
+    if (int e = gsr_exclusive_scan(tmp, tmp, n, &counters->num_pairs, scan_ws, scan_bytes, stream)) return e;
+    hipLaunchKernelGGL(scatter_u32_kernel, grid, block, 0, st, tmp, order, slot_base, n);
+    return gsr_check_launch("bin_offsets");
+}
+
+extern "C" size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs)
+{
+    const size_t arr = align256((size_t)(num_pairs ? num_pairs : 1) * sizeof(uint32_t));
+    return 5 * arr + gsr_sort_workspace_bytes(num_pairs);
+}
+
+extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_base, const int32_t *bbox,
+                             const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
+                             uint32_t *tile_offsets, uint32_t *pair_pos, uint32_t *sorted_gauss,
+                             float *stream_rec, void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    ViewK v;
+    if (int e = gsr_make_view(view_host, &v)) return e;
+    if (!tile_offsets) { gsr_set_error("gsr_bin_lists: null tile_offsets"); return GSR_ERR_ARG; }
+    if (num_pairs == 0) {
+        (void)hipMemsetAsync(tile_offsets, 0, (size_t)(v.T + 1) * sizeof(uint32_t), st);
+        return GSR_OK;
+    }
+    if (!workspace || workspace_bytes < gsr_bin_lists_workspace_bytes(num_pairs)) {
+        gsr_set_error("gsr_bin_lists: workspace too small");
+        return GSR_ERR_ARG;
+    }
+    if (!slot_base || !bbox || !ntiles || !rec || !pair_pos || !sorted_gauss || !stream_rec) {
+        gsr_set_error("gsr_bin_lists: null pointer");
+        return GSR_ERR_ARG;
+    }
+    const size_t arr = align256((size_t)num_pairs * sizeof(uint32_t));
+    char *ws = (char *)workspace;
+    uint32_t *tile_key = (uint32_t *)ws;
+    uint32_t *slot_id = (uint32_t *)(ws + arr);
+    uint32_t *owner = (uint32_t *)(ws + 2 * arr);
+    uint32_t *sorted_tile = (uint32_t *)(ws + 3 * arr);
+    uint32_t *sorted_slot = (uint32_t *)(ws + 4 * arr);
+    void *sort_ws = ws + 5 * arr;
+    const size_t sort_bytes = workspace_bytes - 5 * arr;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, slot_base, bbox, ntiles,
+                       tile_key, slot_id, owner, num_pairs);
+    if (int e = gsr_sort_pairs(tile_key, slot_id, sorted_tile, sorted_slot, num_pairs, 0, bits_for((uint32_t)v.T),
+                               sort_ws, sort_bytes, stream))
+        return e;
+    hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, sorted_tile,
+                       sorted_slot, owner, rec, num_pairs, (uint32_t)v.T, tile_offsets, pair_pos, sorted_gauss,
+                       stream_rec);
+    return gsr_check_launch("bin_lists");
+}

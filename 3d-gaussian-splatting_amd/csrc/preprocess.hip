@@ -1,0 +1,566 @@
+// Stage 1 of the splat path: one thread per Gaussian.
+//
+// Forward: activations, 3-D covariance, projection + cull, 2-D covariance and its inverse,
+// SH colour, radius, integer bounding box, tile count; writes the 48-byte splat record the
+// compositing kernels stream.  Backward: sums a Gaussian's per-tile gradient records and chains
+// them to the raw parameters.
+//
+// The discrete outputs (visibility mask, depth key, bounding box) must equal the reference's bit
+// for bit, so every fp32 operation feeding them is written out one IEEE operation at a time in
+// the order the reference's tensor ops apply them:
+//   [N,4]@[4,4] and [2M,3]@[3,3] products (sgemm)  : acc = a0*b0; acc = fma(ak, bk, acc)
+//   3x3 / 2x3 batched products (small-matrix loop)  : acc = 0;     acc = acc + ak*bk
+//   F.normalize                                     : sum of squares left to right
+//   exp of the log-scales                           : correctly rounded, (float)exp((double)x)
+// This file is compiled with -ffp-contract=off; fused operations appear only as __fmaf_rn.
+#include "gsr_common.hpp"
+
+namespace {
+
+__device__ __constant__ const float kC0 = 0.28209479177387814f;
+__device__ __constant__ const float kC1 = 0.4886025119029199f;
+__device__ __constant__ const float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                              -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ const float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                              0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                              -0.5900435899266435f};
+
+struct Geom {
+    float s[3];
+    float qn;
+    float q[4];
+    float R[3][3];
+    float RS[3][3];
+    float cov3[3][3];
+    float c[4];     // clip-space position
+    float ndc[3];
+    float M[2][3];  // J @ W
+    float cov2[4];
+};
+
+__device__ inline float dot4_fma(const float *v, const float *row)
+{
+    float acc = v[0] * row[0];
+    acc = __fmaf_rn(v[1], row[1], acc);
+    acc = __fmaf_rn(v[2], row[2], acc);
+    acc = __fmaf_rn(v[3], row[3], acc);
+    return acc;
+}
+
+// GaussianModel.py:50-56,99-108; Utils/Transform.py:55-63,95-98; Utils/Camera.py:81-87,101-103.
+__device__ inline void geometry(const ViewK &v, const float p[3], const float sr[3], const float qr[4], Geom &g)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g.s[k] = (float)exp((double)sr[k]);
+    float ss = qr[0] * qr[0];
+    ss = ss + qr[1] * qr[1];
+    ss = ss + qr[2] * qr[2];
+    ss = ss + qr[3] * qr[3];
+    float nrm = sqrtf(ss);
+    g.qn = nrm > 1e-12f ? nrm : 1e-12f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.q[k] = qr[k] / g.qn;
+    const float w = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
+    g.R[0][0] = 2.0f * (w * w + x * x) - 1.0f; g.R[0][1] = 2.0f * (x * y - w * z); g.R[0][2] = 2.0f * (x * z + w * y);
+    g.R[1][0] = 2.0f * (x * y + w * z); g.R[1][1] = 2.0f * (w * w + y * y) - 1.0f; g.R[1][2] = 2.0f * (y * z - w * x);
+    g.R[2][0] = 2.0f * (x * z - w * y); g.R[2][1] = 2.0f * (y * z + w * x); g.R[2][2] = 2.0f * (w * w + z * z) - 1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g.RS[i][j] = g.R[i][j] * g.s[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc = acc + g.RS[i][k] * g.RS[j][k];
+            g.cov3[i][j] = acc;
+        }
+    const float ph[4] = {p[0], p[1], p[2], 1.0f};
+    float m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = dot4_fma(ph, &v.w2m[4 * j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g.c[j] = dot4_fma(m, &v.proj[4 * j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g.ndc[j] = g.c[j] / g.c[3];
+    // J is built from the WORLD position; J01 = J10 = 0.
+    float J[2][3];
+    J[0][0] = 1.0f / p[2]; J[0][1] = 0.0f; J[0][2] = (-p[0]) / p[2];
+    J[1][0] = 0.0f; J[1][1] = 1.0f / p[2]; J[1][2] = (-p[1]) / p[2];
+    float t2[2][3], t3[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = J[i][0] * v.w2m[4 * j + 0];
+            acc = __fmaf_rn(J[i][1], v.w2m[4 * j + 1], acc);
+            acc = __fmaf_rn(J[i][2], v.w2m[4 * j + 2], acc);
+            g.M[i][j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc = acc + g.M[i][k] * g.cov3[k][j];
+            t2[i][j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = t2[i][0] * v.w2m[4 * 0 + j];
+            acc = __fmaf_rn(t2[i][1], v.w2m[4 * 1 + j], acc);
+            acc = __fmaf_rn(t2[i][2], v.w2m[4 * 2 + j], acc);
+            t3[i][j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc = acc + t3[i][k] * J[j][k];
+            g.cov2[2 * i + j] = acc;
+        }
+}
+
+// SH basis of an un-normalised direction (Utils/SphericalHarmonic.py:62-88), degree <= 3.
+__device__ inline void sh_basis(int deg, float x, float y, float z, float b[16])
+{
+    b[0] = kC0;
+    if (deg < 1) return;
+    b[1] = -kC1 * y; b[2] = kC1 * z; b[3] = -kC1 * x;
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = kC2[0] * xy; b[5] = kC2[1] * yz; b[6] = kC2[2] * (2.0f * zz - xx - yy);
+    b[7] = kC2[3] * xz; b[8] = kC2[4] * (xx - yy);
+    if (deg < 3) return;
+    b[9] = kC3[0] * y * (3.0f * xx - yy);
+    b[10] = kC3[1] * xy * z;
+    b[11] = kC3[2] * y * (4.0f * zz - xx - yy);
+    b[12] = kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    b[13] = kC3[4] * x * (4.0f * zz - xx - yy);
+    b[14] = kC3[5] * z * (xx - yy);
+    b[15] = kC3[6] * x * (xx - 3.0f * yy);
+}
+
+// d(sum_k co[k] basis_k)/d(x,y,z)
+__device__ inline void sh_dir_grad(int deg, float x, float y, float z, const float co[16], float d[3])
+{
+    d[0] = d[1] = d[2] = 0.0f;
+    if (deg < 1) return;
+    d[1] += -kC1 * co[1]; d[2] += kC1 * co[2]; d[0] += -kC1 * co[3];
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    d[0] += kC2[0] * y * co[4] + kC2[2] * -2.0f * x * co[6] + kC2[3] * z * co[7] + kC2[4] * 2.0f * x * co[8];
+    d[1] += kC2[0] * x * co[4] + kC2[1] * z * co[5] + kC2[2] * -2.0f * y * co[6] + kC2[4] * -2.0f * y * co[8];
+    d[2] += kC2[1] * y * co[5] + kC2[2] * 4.0f * z * co[6] + kC2[3] * x * co[7];
+    if (deg < 3) return;
+    d[0] += kC3[0] * 6.0f * x * y * co[9] + kC3[1] * y * z * co[10] + kC3[2] * -2.0f * x * y * co[11] +
+            kC3[3] * -6.0f * x * z * co[12] + kC3[4] * (4.0f * zz - 3.0f * xx - yy) * co[13] +
+            kC3[5] * 2.0f * x * z * co[14] + kC3[6] * (3.0f * xx - 3.0f * yy) * co[15];
+    d[1] += kC3[0] * (3.0f * xx - 3.0f * yy) * co[9] + kC3[1] * x * z * co[10] +
+            kC3[2] * (4.0f * zz - xx - 3.0f * yy) * co[11] + kC3[3] * -6.0f * y * z * co[12] +
+            kC3[4] * -2.0f * x * y * co[13] + kC3[5] * -2.0f * y * z * co[14] + kC3[6] * -6.0f * x * y * co[15];
+    d[2] += kC3[1] * x * y * co[10] + kC3[2] * 8.0f * y * z * co[11] +
+            kC3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy) * co[12] + kC3[4] * 8.0f * x * z * co[13] +
+            kC3[5] * (xx - yy) * co[14];
+}
+
+// Zero-pivot test of a 2x2 LU with partial pivoting: the condition under which the reference's
+// torch.linalg.inv raises (Utils/Probability.py:15).
+__device__ inline bool lu2_singular(const float c[4])
+{
+    const float a = c[0], b = c[1], cc = c[2], d = c[3];
+    if (fabsf(a) >= fabsf(cc)) {
+        if (a == 0.0f) return true;
+        return (d - (cc / a) * b) == 0.0f;
+    }
+    return (b - (a / cc) * d) == 0.0f;
+}
+
+__device__ inline void load_sh(const float *sh, int i, int K, float co[3][16])
+{
+    const float4 *src = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v4 * 4 < K) t = src[c * 4 + v4];
+            co[c][v4 * 4 + 0] = t.x; co[c][v4 * 4 + 1] = t.y; co[c][v4 * 4 + 2] = t.z; co[c][v4 * 4 + 3] = t.w;
+        }
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
+    ViewK v, const float *__restrict__ coords, const float *__restrict__ scale_raw,
+    const float *__restrict__ rot_raw, const float *__restrict__ opac_raw, const float *__restrict__ sh,
+    const float *__restrict__ screen_coords, uint8_t *__restrict__ mask, uint32_t *__restrict__ depth_key,
+    float *__restrict__ pos2d, float *__restrict__ cov2d, float *__restrict__ radius,
+    int32_t *__restrict__ bbox, uint32_t *__restrict__ ntiles, float *__restrict__ rec,
+    gsr_counters *__restrict__ counters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool vis = false;
+    bool singular = false;
+    if (i < v.n) {
+        const float p[3] = {coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
+        const float sr[3] = {scale_raw[3 * i], scale_raw[3 * i + 1], scale_raw[3 * i + 2]};
+        const float4 q4 = reinterpret_cast<const float4 *>(rot_raw)[i];
+        const float qr[4] = {q4.x, q4.y, q4.z, q4.w};
+        Geom g;
+        geometry(v, p, sr, qr, g);
+        // Utils/Camera.py:106-108 (NaN compares false: culled)
+        vis = (g.ndc[2] >= 0.1f) && (-1.3f <= g.ndc[0]) && (g.ndc[0] <= 1.3f) && (-1.3f <= g.ndc[1]) &&
+              (g.ndc[1] <= 1.3f);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        float px = 0.f, py = 0.f, pz = 0.f, rad = 0.f;
+        float cv[4] = {0.f, 0.f, 0.f, 0.f};
+        int bx[4] = {0, 0, 0, 0};
+        uint32_t nt = 0, key = 0xFFFFFFFFu;
+        if (vis) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            if (screen_coords) { sx = screen_coords[3 * i]; sy = screen_coords[3 * i + 1]; sz = screen_coords[3 * i + 2]; }
+            // Utils/Camera.py:111-115
+            px = sx + g.ndc[0]; py = sy + g.ndc[1]; pz = sz + g.ndc[2];
+            px = (0.5f * (px + 1.0f)) * v.Wf;
+            py = (1.0f - 0.5f * (py + 1.0f)) * v.Hf;
+            key = __float_as_uint(pz);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cv[k] = g.cov2[k];
+            // GaussianRenderer.py:40-44
+            const float a = cv[0], b = cv[1], c = cv[2], d = cv[3];
+            const float trace = a + d;
+            const float det = a * d - b * c;
+            const float term1 = 0.5f * trace;
+            float disc = trace * trace - 4.0f * det;
+            if (disc < 0.0f) disc = 0.0f;
+            const float term2 = 0.5f * sqrtf(disc);
+            const float lo = term1 - term2, hi = term1 + term2;
+            rad = 3.0f * sqrtf(lo > hi ? lo : hi);
+            // Utils/Screen.py:33-36: clamp, then truncate; a NaN edge gives an empty box
+            const float e[4] = {px - rad, py - rad, px + rad, py + rad};
+            const float lim[4] = {v.Wf, v.Hf, v.Wf, v.Hf};
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = e[k];
+                if (t != t) { bad = true; t = 0.0f; }
+                if (t < 0.0f) t = 0.0f;
+                if (t > lim[k]) t = lim[k];
+                bx[k] = (int)t;
+            }
+            if (bad) bx[0] = bx[1] = bx[2] = bx[3] = 0;
+            int x0, x1, y0, y1;
+            gsr_tile_span(bx[0], bx[2], v.L, x0, x1);
+            gsr_tile_span(bx[1], bx[3], v.L, y0, y1);
+            nt = (uint32_t)(x1 - x0 + 1) * (uint32_t)(y1 - y0 + 1);
+            singular = nt > 0 && lu2_singular(cv);
+            // inverse 2x2, pre-scaled so that G = exp2(A' dx^2 + B' dx dy + D' dy^2)
+            const float idet = 1.0f / det;
+            const float kk = -0.5f * 1.4426950408889634f;
+            const float ia = d * idet, ib = -b * idet, ic = -c * idet, id = a * idet;
+            // GaussianModel.py:58-60
+            const float o = 1.0f / (1.0f + expf(-opac_raw[i]));
+            // GaussianRenderer.py:71-74
+            float co[3][16], bs[16];
+            load_sh(sh, i, v.K, co);
+            sh_basis(v.deg, p[0] - v.cam[0], p[1] - v.cam[1], p[2] - v.cam[2], bs);
+            float col[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < v.K) acc += bs[k] * co[ch][k];
+                acc += 0.5f;
+                col[ch] = acc < 0.0f ? 0.0f : acc;
+            }
+            r0 = make_float4(px, py, kk * ia, kk * (ib + ic));
+            r1 = make_float4(kk * id, o, col[0], col[1]);
+            r2 = make_float4(col[2], ia, 0.5f * (ib + ic), id);
+        }
+        mask[i] = vis ? 1 : 0;
+        depth_key[i] = key;
+        pos2d[3 * i] = px; pos2d[3 * i + 1] = py; pos2d[3 * i + 2] = pz;
+        reinterpret_cast<float4 *>(cov2d)[i] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+        radius[i] = rad;
+        reinterpret_cast<int4 *>(bbox)[i] = make_int4(bx[0], bx[1], bx[2], bx[3]);
+        ntiles[i] = nt;
+        float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)i * GSR_REC_FLOATS);
+        dst[0] = r0; dst[1] = r1; dst[2] = r2;
+    }
+    // one atomic per wave for the visible count; error flag only when set
+    const unsigned long long bal = __ballot(vis);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counters->num_visible, (uint32_t)__popcll(bal));
+    if (singular) atomicOr(&counters->error, 1u);
+}
+
+template <bool ACC>
+__device__ inline void put(float *dst, float v)
+{
+    if (ACC) *dst += v; else *dst = v;
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
+    ViewK v, const float *__restrict__ coords, const float *__restrict__ scale_raw,
+    const float *__restrict__ rot_raw, const float *__restrict__ opac_raw, const float *__restrict__ sh,
+    const uint8_t *__restrict__ mask, const uint32_t *__restrict__ slot_base,
+    const uint32_t *__restrict__ ntiles, const uint32_t *__restrict__ pair_pos,
+    const float *__restrict__ pairgrad, float *__restrict__ g_coords, float *__restrict__ g_scale,
+    float *__restrict__ g_rot, float *__restrict__ g_opac, float *__restrict__ g_sh,
+    float *__restrict__ g_screen)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.n) return;
+    float gc[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, gr[4] = {0.f, 0.f, 0.f, 0.f};
+    float gsc[2] = {0.f, 0.f}, go = 0.f;
+    float gsh[3][16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) gsh[c][k] = 0.f;
+
+    if (mask[i]) {
+        // sum of this Gaussian's per-tile records, in slot order (fixed => reproducible)
+        double acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+        const uint32_t nt = ntiles[i], e0 = slot_base[i];
+        for (uint32_t j = 0; j < nt; ++j) {
+            const uint32_t pp = pair_pos[e0 + j];
+            const float4 *src = reinterpret_cast<const float4 *>(pairgrad + (size_t)pp * GSR_PAIRGRAD_FLOATS);
+            const float4 a = src[0], b = src[1];
+            const float c8 = pairgrad[(size_t)pp * GSR_PAIRGRAD_FLOATS + 8];
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c8;
+        }
+        // With h = -2 dL/d(exponent) per pixel, d = centre - pixel, C = inv(cov2) (symmetric part) and
+        // v = C d, the records hold: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2,
+        // dL/d(opacity), dL/d(colour).  exponent = d^T C d, so
+        //   dL/d(centre) = sum (-h/2) (2 v) = -sum h v,     dL/d(cov2) = sum (-h/2) (-v v^T) = 1/2 sum h v v^T.
+        const double d_px = -acc[0], d_py = -acc[1];
+        const double D[2][2] = {{0.5 * acc[2], 0.5 * acc[3]}, {0.5 * acc[3], 0.5 * acc[4]}};
+        const double d_o = acc[5];
+        const double d_col[3] = {acc[6], acc[7], acc[8]};
+
+        const float p[3] = {coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
+        const float sr[3] = {scale_raw[3 * i], scale_raw[3 * i + 1], scale_raw[3 * i + 2]};
+        const float4 q4 = reinterpret_cast<const float4 *>(rot_raw)[i];
+        const float qr[4] = {q4.x, q4.y, q4.z, q4.w};
+        Geom g;
+        geometry(v, p, sr, qr, g);
+        double gp[3] = {0.0, 0.0, 0.0};
+        // opacity = sigmoid(raw)
+        const float o = 1.0f / (1.0f + expf(-opac_raw[i]));
+        go = (float)(d_o * (double)(o * (1.0f - o)));
+
+        // colour = max(sh . basis + 0.5, 0): gradient where the sum is >= 0 (torch.clamp rule)
+        {
+            float co[3][16], bs[16];
+            load_sh(sh, i, v.K, co);
+            const float dx = p[0] - v.cam[0], dy = p[1] - v.cam[1], dz = p[2] - v.cam[2];
+            sh_basis(v.deg, dx, dy, dz, bs);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float a = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < v.K) a += bs[k] * co[ch][k];
+                a += 0.5f;
+                if (a >= 0.0f) {
+                    const float dc = (float)d_col[ch];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k < v.K) gsh[ch][k] = dc * bs[k];
+                    float dd[3];
+                    sh_dir_grad(v.deg, dx, dy, dz, co[ch], dd);
+                    gp[0] += d_col[ch] * (double)dd[0];
+                    gp[1] += d_col[ch] * (double)dd[1];
+                    gp[2] += d_col[ch] * (double)dd[2];
+                }
+            }
+        }
+        // pixel centre -> NDC (+ screen_coords) -> clip -> world  (Utils/Camera.py:102-115)
+        {
+            const double dn[3] = {d_px * 0.5 * (double)v.Wf, d_py * -0.5 * (double)v.Hf, 0.0};
+            gsc[0] = (float)dn[0]; gsc[1] = (float)dn[1];
+            const double c3 = (double)g.c[3];
+            double dc[4];
+            dc[3] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { dc[j] = dn[j] / c3; dc[3] -= dn[j] * (double)g.c[j] / (c3 * c3); }
+            double dm[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dm[k] = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dm[k] += dc[j] * (double)v.proj[4 * j + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gp[k] += dm[j] * (double)v.w2m[4 * j + k];
+        }
+        // cov2 = M S M^T with M = J W
+        double dS[3][3], dM[2][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) s += (double)g.M[r][a] * D[r][c] * (double)g.M[c][b];
+                dS[a][b] = s;
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double s = 0.0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        s += D[r][c] * (double)g.M[c][b] * (double)g.cov3[a][b] +
+                             D[c][r] * (double)g.M[c][b] * (double)g.cov3[b][a];
+                dM[r][a] = s;
+            }
+        {
+            // M = J W, W[k][j] = w2m[j][k]; J00 = J11 = 1/z, J02 = -x/z, J12 = -y/z (world x,y,z)
+            double dJ[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dJ[r][k] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) dJ[r][k] += dM[r][j] * (double)v.w2m[4 * j + k];
+                }
+            const double x = p[0], y = p[1], z = p[2];
+            gp[0] += dJ[0][2] * (-1.0 / z);
+            gp[1] += dJ[1][2] * (-1.0 / z);
+            gp[2] += (dJ[0][0] + dJ[1][1]) * (-1.0 / (z * z)) + dJ[0][2] * (x / (z * z)) + dJ[1][2] * (y / (z * z));
+        }
+        {
+            // cov3 = RS RS^T, RS = R diag(s), s = exp(raw), R = R(q), q = raw / max(|raw|, eps)
+            double dRS[3][3], dR[3][3], ds[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) s += (dS[a][b] + dS[b][a]) * (double)g.RS[b][k];
+                    dRS[a][k] = s;
+                }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dR[a][k] = dRS[a][k] * (double)g.s[k];
+                    ds[k] += dRS[a][k] * (double)g.R[a][k];
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gs[k] = (float)(ds[k] * (double)g.s[k]);
+            const double w = g.q[0], x = g.q[1], y = g.q[2], z = g.q[3];
+            double dq[4];
+            dq[0] = 4 * w * (dR[0][0] + dR[1][1] + dR[2][2]) +
+                    2 * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            dq[1] = 4 * x * dR[0][0] +
+                    2 * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - w * dR[1][2] + z * dR[2][0] + w * dR[2][1]);
+            dq[2] = 4 * y * dR[1][1] +
+                    2 * (x * dR[0][1] + w * dR[0][2] + x * dR[1][0] + z * dR[1][2] - w * dR[2][0] + z * dR[2][1]);
+            dq[3] = 4 * z * dR[2][2] +
+                    2 * (-w * dR[0][1] + x * dR[0][2] + w * dR[1][0] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+            const double nrm = g.qn;
+            if (g.qn > 1e-12f) {
+                const double qd = w * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
+                const double qq[4] = {w, x, y, z};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gr[k] = (float)((dq[k] - qq[k] * qd) / nrm);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gr[k] = (float)(dq[k] / nrm);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gc[k] = (float)gp[k];
+    }
+
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { put<ACC>(g_coords + 3 * i + k, gc[k]); put<ACC>(g_scale + 3 * i + k, gs[k]); }
+    {
+        float4 *dst = reinterpret_cast<float4 *>(g_rot) + i;
+        float4 o4 = make_float4(gr[0], gr[1], gr[2], gr[3]);
+        if (ACC) { const float4 t = *dst; o4.x += t.x; o4.y += t.y; o4.z += t.z; o4.w += t.w; }
+        *dst = o4;
+    }
+    put<ACC>(g_opac + i, go);
+    put<ACC>(g_screen + 3 * i, gsc[0]); put<ACC>(g_screen + 3 * i + 1, gsc[1]); put<ACC>(g_screen + 3 * i + 2, 0.0f);
+    float4 *dsh = reinterpret_cast<float4 *>(g_sh + (size_t)i * 48);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            float4 o4 = make_float4(gsh[c][4 * v4], gsh[c][4 * v4 + 1], gsh[c][4 * v4 + 2], gsh[c][4 * v4 + 3]);
+            if (ACC) { const float4 t = dsh[c * 4 + v4]; o4.x += t.x; o4.y += t.y; o4.z += t.z; o4.w += t.w; }
+            dsh[c * 4 + v4] = o4;
+        }
+}
+
+}  // namespace
+
+extern "C" int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
+                                  const float *rot_raw, const float *opac_raw, const float *sh,
+                                  const float *screen_coords, uint8_t *mask, uint32_t *depth_key, float *pos2d,
+                                  float *cov2d, float *radius, int32_t *bbox, uint32_t *ntiles, float *rec,
+                                  gsr_counters *counters, void *stream)
+{
+    ViewK v;
+    if (int e = gsr_make_view(view_host, &v)) return e;
+    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !mask || !depth_key || !pos2d || !cov2d ||
+        !radius || !bbox || !ntiles || !rec || !counters) {
+        gsr_set_error("gsr_preprocess_fwd: null pointer");
+        return GSR_ERR_ARG;
+    }
+    if (v.n == 0) return GSR_OK;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, (hipStream_t)stream, v,
+                       coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, mask, depth_key, pos2d, cov2d,
+                       radius, bbox, ntiles, rec, counters);
+    return gsr_check_launch("preprocess_fwd");
+}
+
+extern "C" int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
+                                  const float *rot_raw, const float *opac_raw, const float *sh,
+                                  const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
+                                  const uint32_t *pair_pos, const float *pairgrad, float *g_coords,
+                                  float *g_scale, float *g_rot, float *g_opac, float *g_sh, float *g_screen,
+                                  int accumulate, void *stream)
+{
+    ViewK v;
+    if (int e = gsr_make_view(view_host, &v)) return e;
+    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !mask || !slot_base || !ntiles || !g_coords ||
+        !g_scale || !g_rot || !g_opac || !g_sh || !g_screen) {
+        gsr_set_error("gsr_preprocess_bwd: null pointer");
+        return GSR_ERR_ARG;
+    }
+    if (v.n == 0) return GSR_OK;
+    const dim3 grid(gsr_div_up(v.n, 256)), block(256);
+    if (accumulate)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, v, coords, scale_raw,
+                           rot_raw, opac_raw, sh, mask, slot_base, ntiles, pair_pos, pairgrad, g_coords, g_scale,
+                           g_rot, g_opac, g_sh, g_screen);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, v, coords, scale_raw,
+                           rot_raw, opac_raw, sh, mask, slot_base, ntiles, pair_pos, pairgrad, g_coords, g_scale,
+                           g_rot, g_opac, g_sh, g_screen);
+    return gsr_check_launch("preprocess_bwd");
+}

@@ -1,0 +1,262 @@
+// Device-wide exclusive scan and stable least-significant-digit radix sort of (u32 key, u32 value)
+// pairs.  Both are bandwidth-bound passes over HBM; wave64 primitives (ballot, shuffles) do the
+// in-block work.  Nothing here allocates: scratch comes from the caller's workspace.
+#include "gsr_common.hpp"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 elements per block
+
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX_SIZE = 1 << RADIX_BITS;
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / GSR_WAVE;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per block
+
+__device__ inline uint32_t wave_inclusive_scan(uint32_t x)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// Exclusive scan across the block of one value per thread; returns the exclusive prefix and the
+// block total.  lds must hold blockDim.x/64 + 1 words.
+__device__ inline uint32_t block_exclusive_scan(uint32_t x, uint32_t *lds, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(x);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < nw; ++w) { const uint32_t t = lds[w]; lds[w] = run; run += t; }
+        lds[nw] = run;
+    }
+    __syncthreads();
+    const uint32_t base = lds[wave];
+    total = lds[nw];
+    __syncthreads();
+    return base + inc - x;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t n,
+                                                                   uint32_t *__restrict__ block_sums)
+{
+    __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) s += in[base + k];
+    uint32_t total;
+    block_exclusive_scan(s, lds, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// One block: exclusive scan of block_sums[0..nb) in place, total to *total_out (may be null).
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ block_sums, uint32_t nb,
+                                                         uint32_t *__restrict__ total_out)
+{
+    __shared__ uint32_t lds[1024 / 64 + 1];
+    uint32_t carry = 0;
+    for (uint32_t start = 0; start < nb; start += 1024) {
+        const uint32_t i = start + threadIdx.x;
+        const uint32_t x = i < nb ? block_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(x, lds, total);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t *__restrict__ in,
+                                                                  uint32_t *__restrict__ out, uint32_t n,
+                                                                  const uint32_t *__restrict__ block_sums)
+{
+    __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0u;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan(s, lds, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+// ---- radix sort -------------------------------------------------------------------------
+
+// hist[digit * nb + block] = number of keys of the block's tile with that digit
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n,
+                                                                  int shift, uint32_t mask, uint32_t nb,
+                                                                  uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[RADIX_SIZE];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = base + it * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+// Stable scatter of one tile.  Wave w owns keys [w*1024, (w+1)*1024) of the tile, item `it` of a
+// wave is the 64 consecutive keys at it*64, so key order = (wave, item, lane).  Ranks inside a
+// wave come from ballots (lanes with an equal digit), per-wave digit counters live in LDS.
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nb,
+    const uint32_t *__restrict__ hist_scanned)
+{
+    __shared__ uint32_t cnt[SORT_WAVES][RADIX_SIZE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+
+    const uint32_t wbase = blockIdx.x * SORT_TILE + wave * (SORT_ITEMS * 64);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t key[SORT_ITEMS], rank[SORT_ITEMS];
+    volatile uint32_t *mycnt = cnt[wave];
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = wbase + it * 64 + lane;
+        const bool valid = i < n;
+        key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        const uint32_t d = (key[it] >> shift) & mask;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t prior = mycnt[d];
+        const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
+        rank[it] = prior + below;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0) mycnt[d] = prior + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        // thread d: global base of digit d for this block, then per-wave exclusive offsets
+        const uint32_t d = threadIdx.x;
+        uint32_t run = hist_scanned[d * nb + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const uint32_t c = cnt[w][d];
+            cnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = wbase + it * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (key[it] >> shift) & mask;
+            const uint32_t pos = cnt[wave][d] + rank[it];
+            keys_out[pos] = key[it];
+            vals_out[pos] = vals_in[i];
+        }
+    }
+}
+
+}  // namespace
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t gsr_scan_workspace_bytes(uint32_t n)
+{
+    return align256((size_t)gsr_div_up(n ? n : 1, SCAN_TILE) * sizeof(uint32_t));
+}
+
+extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (workspace_bytes < gsr_scan_workspace_bytes(n) || !workspace) {
+        gsr_set_error("gsr_exclusive_scan: workspace too small (%zu < %zu)", workspace_bytes,
+                      gsr_scan_workspace_bytes(n));
+        return GSR_ERR_ARG;
+    }
+    if (n == 0) {
+        if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), st);
+        return GSR_OK;
+    }
+    if (!in || !out) { gsr_set_error("gsr_exclusive_scan: null pointer"); return GSR_ERR_ARG; }
+    uint32_t *sums = (uint32_t *)workspace;
+    const uint32_t nb = gsr_div_up(n, SCAN_TILE);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb, total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, out, n, sums);
+    return gsr_check_launch("exclusive_scan");
+}
+
+extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)
+{
+    const uint32_t nb = gsr_div_up(n ? n : 1, SORT_TILE);
+    const size_t hist = align256((size_t)nb * RADIX_SIZE * sizeof(uint32_t));
+    return hist + gsr_scan_workspace_bytes(nb * RADIX_SIZE);
+}
+
+extern "C" int gsr_sort_pairs(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                              uint32_t n, int begin_bit, int end_bit, void *workspace, size_t workspace_bytes,
+                              void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) {
+        gsr_set_error("gsr_sort_pairs: bad bit range [%d,%d)", begin_bit, end_bit);
+        return GSR_ERR_ARG;
+    }
+    if (workspace_bytes < gsr_sort_workspace_bytes(n) || !workspace) {
+        gsr_set_error("gsr_sort_pairs: workspace too small (%zu < %zu)", workspace_bytes, gsr_sort_workspace_bytes(n));
+        return GSR_ERR_ARG;
+    }
+    if (n == 0) return GSR_OK;
+    if (!keys_in || !vals_in || !keys_out || !vals_out) { gsr_set_error("gsr_sort_pairs: null pointer"); return GSR_ERR_ARG; }
+    const uint32_t nb = gsr_div_up(n, SORT_TILE);
+    uint32_t *hist = (uint32_t *)workspace;
+    const size_t hist_bytes = align256((size_t)nb * RADIX_SIZE * sizeof(uint32_t));
+    void *scan_ws = (char *)workspace + hist_bytes;
+    const size_t scan_ws_bytes = workspace_bytes - hist_bytes;
+    uint32_t *ki = keys_in, *vi = vals_in, *ko = keys_out, *vo = vals_out;
+    bool in_out = false;  // where the current data is: false = the *_in buffers
+    for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
+        const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
+        const uint32_t mask = (1u << nbits) - 1u;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
+        if (int e = gsr_exclusive_scan(hist, hist, nb * RADIX_SIZE, nullptr, scan_ws, scan_ws_bytes, stream)) return e;
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(SORT_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask,
+                           nb, hist);
+        uint32_t *t = ki; ki = ko; ko = t;
+        t = vi; vi = vo; vo = t;
+        in_out = !in_out;
+    }
+    if (!in_out) {  // even number of passes (or none): the result sits in the *_in buffers
+        (void)hipMemcpyAsync(keys_out, keys_in, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(vals_out, vals_in, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+    }
+    return gsr_check_launch("sort_pairs");
+}

@@ -1,0 +1,200 @@
+"""The render path as a ``torch.autograd.Function`` over the HIP kernels of ``libgsr.so``.
+
+Replaces the body of ``GaussianRenderer.render`` (``GaussianRenderer.py:52-113``): forward
+produces the image, the visibility mask and the radii; backward produces the gradients of the
+five raw parameter tensors and of ``screen_coords``.  PyTorch only owns the memory and the
+stream; all arithmetic runs in the library.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class ViewSpec:
+    """Per-view constants (host side)."""
+    sh_degree: int
+    width: int
+    height: int
+    tile_length: int
+    w2m: tuple        # 16 floats, row-major world->model
+    proj: tuple       # 16 floats, row-major projection
+    cam_pos: tuple    # 3 floats
+
+    @staticmethod
+    def from_camera(cam, sh_degree: int, tile_length: int) -> "ViewSpec":
+        from .camera import camera_constants
+        w2m, proj, pos = camera_constants(cam)
+        return ViewSpec(int(sh_degree), int(cam.width), int(cam.height), int(tile_length),
+                        tuple(float(x) for x in w2m), tuple(float(x) for x in proj),
+                        tuple(float(x) for x in pos))
+
+
+class SingularCovarianceError(RuntimeError):
+    """A Gaussian that lands in a tile has a singular 2-D covariance.
+
+    The reference raises ``torch.linalg.LinAlgError`` from ``torch.linalg.inv``
+    (``Utils/Probability.py:15``) in this situation."""
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check_param(name, t, shape_tail, n=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a tensor on the GPU (there is no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if tuple(t.shape[1:]) != tuple(shape_tail) or (n is not None and t.shape[0] != n):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected [N,{','.join(map(str, shape_tail))}]")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class RenderState:
+    """Everything one forward leaves behind for inspection and for the backward."""
+    __slots__ = ("view", "cview", "n", "num_visible", "num_pairs", "mask_u8", "pos2d", "cov2d", "radius_full",
+                 "bbox", "ntiles", "rec", "order", "slot_base", "tile_offsets", "pair_pos", "sorted_gauss",
+                 "stream_rec", "final_T", "img", "pairgrad")
+
+    def __init__(self):
+        for s in self.__slots__:
+            setattr(self, s, None)
+
+
+def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec) -> RenderState:
+    """Stage 1 -> binning/sort -> compositing.  One host sync (reads 3 counters) in the middle,
+    needed to size the per-pair buffers."""
+    lib = _lib.load()
+    dev = coords.device
+    n = coords.shape[0]
+    coords = _check_param("coords", coords, (3,))
+    scale_raw = _check_param("scale", scale_raw, (3,), n)
+    rot_raw = _check_param("rotation", rot_raw, (4,), n)
+    if opac_raw.dim() == 1:
+        opac_raw = opac_raw.unsqueeze(1)
+    opac_raw = _check_param("opacity", opac_raw, (1,), n)
+    sh = _check_param("sh", sh, (3, 16), n)
+    if screen_coords is not None:
+        screen_coords = _check_param("screen_coords", screen_coords, (3,), n)
+    st = RenderState()
+    st.view, st.n = view, n
+    cv = _lib.make_view(n, view.sh_degree, view.width, view.height, view.tile_length, view.w2m, view.proj, view.cam_pos)
+    st.cview = cv
+    stream = _stream(dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    st.mask_u8 = torch.empty(n, dtype=torch.uint8, device=dev)
+    depth_key = torch.empty(n, **i32)
+    st.pos2d = torch.empty(n, 3, **f32)
+    st.cov2d = torch.empty(n, 4, **f32)
+    st.radius_full = torch.empty(n, **f32)
+    st.bbox = torch.empty(n, 4, **i32)
+    st.ntiles = torch.empty(n, **i32)
+    st.rec = torch.empty(n, _lib.REC_FLOATS, **f32)
+    counters = torch.zeros(8, **i32)
+    _lib.check(lib.gsr_preprocess_fwd(cv, _ptr(coords), _ptr(scale_raw), _ptr(rot_raw), _ptr(opac_raw), _ptr(sh),
+                                      _ptr(screen_coords), _ptr(st.mask_u8), _ptr(depth_key), _ptr(st.pos2d),
+                                      _ptr(st.cov2d), _ptr(st.radius_full), _ptr(st.bbox), _ptr(st.ntiles),
+                                      _ptr(st.rec), _ptr(counters), stream), "gsr_preprocess_fwd")
+    st.order = torch.empty(n, **i32)
+    st.slot_base = torch.empty(n, **i32)
+    ws_bytes = int(lib.gsr_bin_offsets_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.gsr_bin_offsets(_ptr(depth_key), _ptr(st.ntiles), n, _ptr(st.order), _ptr(st.slot_base),
+                                   _ptr(counters), _ptr(ws), ws_bytes, stream), "gsr_bin_offsets")
+    host = counters.cpu()          # the one synchronisation of the forward
+    st.num_visible, st.num_pairs, err = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2])
+    if err & 1:
+        raise SingularCovarianceError("singular 2-D covariance in a Gaussian that lands in a tile")
+    if st.num_visible == 0:
+        return st
+    T = ((view.width + view.tile_length - 1) // view.tile_length) * ((view.height + view.tile_length - 1) // view.tile_length)
+    I = st.num_pairs
+    st.tile_offsets = torch.empty(T + 1, **i32)
+    st.pair_pos = torch.empty(max(I, 1), **i32)
+    st.sorted_gauss = torch.empty(max(I, 1), **i32)
+    st.stream_rec = torch.empty(max(I, 1), _lib.REC_FLOATS, **f32)
+    ws_bytes = int(lib.gsr_bin_lists_workspace_bytes(I))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.gsr_bin_lists(cv, _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
+                                 _ptr(st.tile_offsets), _ptr(st.pair_pos), _ptr(st.sorted_gauss),
+                                 _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream), "gsr_bin_lists")
+    st.img = torch.empty(view.width, view.height, 3, **f32)
+    st.final_T = torch.empty(view.width, view.height, **f32)
+    _lib.check(lib.gsr_composite_fwd(cv, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.img), _ptr(st.final_T),
+                                     stream), "gsr_composite_fwd")
+    return st
+
+
+def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh, dimg, accumulate_into=None):
+    """Compositing backward + stage-1 backward.  Returns the six dense gradients
+    (coords, scale, rotation, opacity[N,1], sh, screen_coords).  ``accumulate_into`` may hold six
+    existing buffers to add to (view minibatches)."""
+    lib = _lib.load()
+    dev = coords.device
+    n = st.n
+    stream = _stream(dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    dimg = dimg.to(torch.float32).contiguous()
+    I = st.num_pairs
+    pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
+    _lib.check(lib.gsr_composite_bwd(st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.final_T),
+                                     _ptr(dimg), I, _ptr(pairgrad), stream), "gsr_composite_bwd")
+    st.pairgrad = pairgrad
+    if accumulate_into is None:
+        grads = (torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32),
+                 torch.empty(n, 1, **f32), torch.empty(n, 3, 16, **f32), torch.empty(n, 3, **f32))
+        acc = 0
+    else:
+        grads, acc = accumulate_into, 1
+    if opac_raw.dim() == 1:
+        opac_raw = opac_raw.unsqueeze(1)
+    _lib.check(lib.gsr_preprocess_bwd(st.cview, _ptr(coords.contiguous()), _ptr(scale_raw.contiguous()),
+                                      _ptr(rot_raw.contiguous()), _ptr(opac_raw.contiguous()), _ptr(sh.contiguous()),
+                                      _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(st.pair_pos),
+                                      _ptr(pairgrad), *[_ptr(g) for g in grads], acc, stream), "gsr_preprocess_bwd")
+    return grads
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view):
+        st = forward_pipeline(coords.detach(), scale_raw.detach(), rot_raw.detach(), opac_raw.detach(), sh.detach(),
+                              None if screen_coords is None else screen_coords.detach(), view)
+        ctx.state = st
+        mask = st.mask_u8.bool()
+        if st.num_visible == 0:
+            ctx.mark_non_differentiable(mask)
+            return coords.new_zeros(0), mask, coords.new_zeros(0)
+        ctx.save_for_backward(coords, scale_raw, rot_raw, opac_raw, sh)
+        radius = st.radius_full[mask]          # length M, like get_radius on the culled set
+        ctx.mark_non_differentiable(mask, radius)
+        return st.img, mask, radius
+
+    @staticmethod
+    def backward(ctx, dimg, _dmask, _dradius):
+        st = ctx.state
+        if st.num_visible == 0:
+            return (None,) * 7
+        coords, scale_raw, rot_raw, opac_raw, sh = ctx.saved_tensors
+        g = backward_pipeline(st, coords, scale_raw, rot_raw, opac_raw, sh, dimg)
+        g_opac = g[3] if opac_raw.dim() == 2 else g[3].squeeze(1)
+        need = ctx.needs_input_grad
+        out = [g[0], g[1], g[2], g_opac, g[4], g[5]]
+        return tuple(o if need[i] else None for i, o in enumerate(out)) + (None,)
+
+
+def rasterize(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec):
+    """-> (img [W,H,3], mask [N] bool, radius [M]) or (None, mask, None) when nothing is visible."""
+    img, mask, radius = _Rasterize.apply(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view)
+    if img.numel() == 0:
+        return None, mask, None
+    return img, mask, radius

@@ -1,0 +1,154 @@
+/*
+ * gsr.h - C ABI of libgsr.so, the MI355X (gfx950) Gaussian-splat rasterizer.
+ *
+ * The reference has no FFI: its render path is the Python method
+ * GaussianRenderer.render (GaussianRenderer.py:52-113) built from ATen ops.  Each entry point
+ * below replaces the group of reference statements cited in its comment; the Python
+ * autograd.Function in 3d-gaussian-splatting_amd/rasterizer.py binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all buffers (inputs, outputs, workspaces) are allocated by the caller; the library
+ *     allocates nothing and keeps no state between calls;
+ *   - every kernel is enqueued on `stream` (a hipStream_t passed as void*); no call blocks;
+ *   - return value: 0 on success, a negative GSR_ERR_* code otherwise (gsr_last_error() gives
+ *     the text for the calling thread);
+ *   - "N-indexed" = one row per Gaussian of the model (size, not capacity);
+ *   - images are [width][height][3] fp32, x (width) is the slow axis (GaussianRenderer.py:84).
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_ERR_ARG (-1)
+#define GSR_ERR_SINGULAR (-2) /* reported through gsr_counters.error, see below */
+#define GSR_ERR_LAUNCH (-3)
+
+/* One view.  The two matrices are built on the host (Utils/Camera.py:25-28). */
+typedef struct gsr_view {
+    int32_t n;           /* Gaussians */
+    int32_t sh_degree;   /* 0..3 (GaussianModel.curr_sh_degree) */
+    int32_t width;       /* cam.width  (slow axis) */
+    int32_t height;      /* cam.height (fast axis) */
+    int32_t tile_length; /* edge of a reference tile, GaussianRenderer.py:52 */
+    float w2m[16];       /* cam.world2model_matrix, row-major */
+    float proj[16];      /* cam.projection_matrix, row-major */
+    float cam_pos[3];    /* cam.transform.position */
+} gsr_view;
+
+/* Device-side counters written by gsr_preprocess_fwd / gsr_bin_offsets (8 x u32). */
+typedef struct gsr_counters {
+    uint32_t num_visible; /* M = mask.sum() */
+    uint32_t num_pairs;   /* I = sum over tiles of list length */
+    uint32_t error;       /* bit 0: a Gaussian that lands in a tile has a singular 2-D covariance
+                             (the reference raises in torch.linalg.inv, Utils/Probability.py:15) */
+    uint32_t reserved[5];
+} gsr_counters;
+
+/* Per-Gaussian splat record produced by stage 1 and consumed by the compositing kernels. */
+/* x, y, A', B', D', opacity, r, g, b, a, (b+c)/2, d   (48 bytes).  [a b; c d] = inverse 2-D
+ * covariance; A' = k a, B' = k (b+c), D' = k d with k = -log2(e)/2, so G = exp2(A'dx^2+B'dxdy+D'dy^2) */
+#define GSR_REC_FLOATS 12
+/* Per-(tile,Gaussian) gradient record produced by the compositing backward. */
+/* With h = -2 dL/d(exponent) per pixel, d = centre - pixel and v = inverse covariance * d:
+ * sum h v_x, sum h v_y, sum h v_x v_x, sum h v_x v_y, sum h v_y v_y, dL/d(opacity), dL/d(r,g,b),
+ * pad x3 */
+#define GSR_PAIRGRAD_FLOATS 12
+
+const char *gsr_last_error(void);
+int gsr_version(void);
+
+/* ---- stage 1: per-Gaussian ------------------------------------------------------------
+ * Replaces: GaussianModel.py:42-65,99-108 (activations, cov3d), Utils/Transform.py:41-100,
+ * Utils/Camera.py:89-117 + 74-87 (project, cull, viewport, cov2d), GaussianRenderer.py:70-77
+ * (opacity, SH colour, radius), Utils/Screen.py:30-36 (integer bounding boxes).
+ * Outputs (N-indexed): mask u8, depth_key u32 (bits of the NDC depth, 0xFFFFFFFF when culled),
+ * pos2d[N,3], cov2d[N,4], radius[N], bbox[N,4] i32 (xmin,ymin,xmax,ymax), ntiles[N] u32,
+ * rec[N,12].  counters->num_visible and ->error are accumulated (zero them first).
+ * screen_coords may be NULL (= zeros, GaussianRenderer.py:64). */
+int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
+                       const float *rot_raw, const float *opac_raw, const float *sh,
+                       const float *screen_coords, uint8_t *mask, uint32_t *depth_key,
+                       float *pos2d, float *cov2d, float *radius, int32_t *bbox, uint32_t *ntiles,
+                       float *rec, gsr_counters *counters, void *stream);
+
+/* Backward of stage 1.  Replaces the autograd graph of the statements listed above
+ * (Trainer.py:57).  pairgrad[I,12] holds one gradient record per (tile, Gaussian) pair at the
+ * pair's position in the sorted stream; Gaussian g owns emission slots slot_base[g] ..
+ * slot_base[g]+ntiles[g], and pair_pos[e] maps slot e to its position.  A Gaussian's records
+ * are summed in slot order, so the result is reproducible run to run.
+ * Writes (or, with accumulate != 0, adds to) the dense gradients of the raw parameters:
+ * g_coords[N,3] g_scale[N,3] g_rot[N,4] g_opac[N] g_sh[N,3,16] g_screen[N,3]
+ * (g_sh beyond the active degree, g_screen[:,2] and the rows of culled Gaussians are 0). */
+int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
+                       const float *rot_raw, const float *opac_raw, const float *sh,
+                       const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
+                       const uint32_t *pair_pos, const float *pairgrad, float *g_coords,
+                       float *g_scale, float *g_rot, float *g_opac, float *g_sh, float *g_screen,
+                       int accumulate, void *stream);
+
+/* ---- stage 2: binning and sorting -----------------------------------------------------
+ * Replaces Utils/Screen.py:38-62 (tile geometry + membership masks) and the per-tile argsort
+ * with its gathers (GaussianRenderer.py:85-95).  The (tile, depth) radix sort is least-
+ * significant-digit first: the depth digits are sorted once per Gaussian (before a Gaussian is
+ * duplicated into its tiles), the tile digits once per pair. */
+
+/* bytes of scratch gsr_sort_pairs needs for n items */
+size_t gsr_sort_workspace_bytes(uint32_t n);
+/* Stable LSD radix sort of (key,value) u32 pairs on key bits [begin_bit, end_bit).
+ * keys_in/vals_in are clobbered; the result is in keys_out/vals_out. */
+int gsr_sort_pairs(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                   uint32_t n, int begin_bit, int end_bit, void *workspace, size_t workspace_bytes,
+                   void *stream);
+/* bytes of scratch gsr_exclusive_scan needs */
+size_t gsr_scan_workspace_bytes(uint32_t n);
+/* out[i] = sum(in[0..i)); *total (device, may be NULL) = sum(in[0..n)).  in == out allowed. */
+int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* Depth order of the Gaussians and the slot ranges of their pairs.
+ * order[N]: Gaussian indices by (depth_key, index) ascending - visible ones first;
+ * slot_base[N] (N-indexed): first emission slot of each Gaussian; slots follow depth order, so
+ * slot_base[order[s]] is the exclusive scan of ntiles[order[s]]; counters->num_pairs = total.
+ * depth_key is clobbered.  workspace: gsr_bin_offsets_workspace_bytes(n). */
+size_t gsr_bin_offsets_workspace_bytes(uint32_t n);
+int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uint32_t *order,
+                    uint32_t *slot_base, gsr_counters *counters, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* Per-tile lists.  num_pairs must be the value read back from counters->num_pairs.
+ * Outputs: tile_offsets[T+1] u32 (tile id = yi + n_block_h * xi, Utils/Screen.py:38-39),
+ * pair_pos[I] (sorted position of slot e), sorted_gauss[I] (Gaussian index at each sorted
+ * position - the concatenated per-tile depth-ordered lists), stream_rec[I,12] (the splat records
+ * in that order).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
+size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs);
+int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_base, const int32_t *bbox,
+                  const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
+                  uint32_t *tile_offsets, uint32_t *pair_pos, uint32_t *sorted_gauss,
+                  float *stream_rec, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- stage 3: compositing -------------------------------------------------------------
+ * Replaces Utils/Probability.py:4-23 and GaussianRenderer.py:100-112 for every tile:
+ * G = exp(-1/2 d^T Sigma^-1 d) at integer pixel coordinates, alpha = clamp(o*G, 0.01, 0.99),
+ * front-to-back blend over the WHOLE list (no early exit, no background).
+ * img[W,H,3] and final_T[W,H] are fully overwritten. */
+int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets,
+                      const float *stream_rec, float *img, float *final_T, void *stream);
+
+/* Backward of the blend (autograd of the statements above).  dimg[W,H,3] is dL/dimg.
+ * pairgrad[I,12] is fully overwritten. */
+int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets,
+                      const float *stream_rec, const float *final_T, const float *dimg,
+                      uint32_t num_pairs, float *pairgrad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -381,151 +381,52 @@ int gso_bin_sort(const gso_view *v, const uint8_t *mask, const int32_t *bbox, co
     return GSO_OK;
 }
 
-/* pixels of one tile are processed in chunks of this many (bounds the scratch) */
-#define PIX_CHUNK 256
+/* Sensitivity probe for the tests: the exponent of every pair is multiplied by this (default 1).
+ * A value like 1 + 1e-7 mimics another correct fp32 evaluation of G and shows which differences
+ * come from discrete clamp decisions rather than from rounding. */
+static double gso_exponent_scale = 1.0;
+void gso_set_exponent_scale(double s) { gso_exponent_scale = s; }
+/* Second probe: uniform relative noise of this amplitude on every transmittance the backward uses. */
+static double gso_t_noise = 0.0;
+void gso_set_t_noise(double s) { gso_t_noise = s; }
 
-/*
- * Stage 3 forward: per tile, front-to-back blend of the whole list for every pixel
- * (GaussianRenderer.py:100-112, Utils/Probability.py:19-22).  img[W,H,3] is overwritten.
- */
+#define GSO_CAT_(a, b) a##b
+#define GSO_CAT(a, b) GSO_CAT_(a, b)
+
+#define REAL float
+#define GSO_EXP expf
+#define GSO_NAME(x) GSO_CAT(x, _f32)
+#include "gso_composite.inc"
+#undef REAL
+#undef GSO_EXP
+#undef GSO_NAME
+
+#define REAL double
+#define GSO_EXP exp
+#define GSO_NAME(x) GSO_CAT(x, _f64)
+#include "gso_composite.inc"
+#undef REAL
+#undef GSO_EXP
+#undef GSO_NAME
+
+/* precise != 0 selects the double-precision pair arithmetic */
 int gso_composite_fwd(const gso_view *v, const int64_t *tile_offsets, const int32_t *tile_lists,
-                      const float *pos2d, const float *conic, const float *opacity,
-                      const float *color, float *img)
+                      const float *pos2d, const float *conic, const float *opacity, const float *color,
+                      float *img, int precise)
 {
-    int L = v->tile_length, W = v->width, H = v->height;
-    int nbh = (H + L - 1) / L;
-    int64_t T = gso_num_tiles(v);
-    memset(img, 0, sizeof(float) * (size_t)W * H * 3);
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int64_t t = 0; t < T; ++t) {
-        int xi = (int)(t / nbh), yi = (int)(t - (int64_t)xi * nbh);
-        int left = xi * L, top = yi * L;
-        int right = left + L < W ? left + L : W, bottom = top + L < H ? top + L : H;
-        int64_t b = tile_offsets[t], e = tile_offsets[t + 1];
-        if (e == b) continue;
-        for (int px = left; px < right; ++px)
-            for (int py = top; py < bottom; ++py) {
-                float Tr = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-                for (int64_t k = b; k < e; ++k) {
-                    int g = tile_lists[k];
-                    float dx = pos2d[3 * g] - (float)px, dy = pos2d[3 * g + 1] - (float)py;
-                    const float *q = conic + 4 * g;
-                    float ex = (dx * q[0] + dy * q[2]) * dx + (dx * q[1] + dy * q[3]) * dy;
-                    float G = expf(-0.5f * ex);
-                    float a = opacity[g] * G;
-                    a = a < 0.01f ? 0.01f : (a > 0.99f ? 0.99f : a);
-                    float wgt = a * Tr;
-                    cr += wgt * color[3 * g]; cg += wgt * color[3 * g + 1]; cb += wgt * color[3 * g + 2];
-                    Tr = Tr * (1.0f - a);
-                }
-                float *o = img + ((size_t)px * H + py) * 3;
-                o[0] = cr; o[1] = cg; o[2] = cb;
-            }
-    }
-    return GSO_OK;
+    return precise ? gso_composite_fwd_f64(v, tile_offsets, tile_lists, pos2d, conic, opacity, color, img)
+                   : gso_composite_fwd_f32(v, tile_offsets, tile_lists, pos2d, conic, opacity, color, img);
 }
 
-/*
- * Stage 3 backward.  dimg[W,H,3] -> per-Gaussian gradients w.r.t. the stage-1 outputs:
- * d_pos2d[N,2] (pixel units), d_conic[N,4], d_opacity[N], d_color[N,3]; all double, zeroed here.
- * Exact gradient of gso_composite_fwd: forward transmittances are recomputed front to back and
- * kept, the suffix sums run back to front.  The clamp passes gradient on the closed interval
- * [0.01, 0.99] (torch.clamp rule).
- */
 int gso_composite_bwd(const gso_view *v, const int64_t *tile_offsets, const int32_t *tile_lists,
-                      const float *pos2d, const float *conic, const float *opacity,
-                      const float *color, const float *dimg, double *d_pos2d, double *d_conic,
-                      double *d_opacity, double *d_color)
+                      const float *pos2d, const float *conic, const float *opacity, const float *color,
+                      const float *dimg, double *d_pos2d, double *d_conic, double *d_opacity,
+                      double *d_color, int precise)
 {
-    int L = v->tile_length, W = v->width, H = v->height, n = v->n;
-    int nbh = (H + L - 1) / L;
-    int64_t T = gso_num_tiles(v);
-    memset(d_pos2d, 0, sizeof(double) * 2 * n);
-    memset(d_conic, 0, sizeof(double) * 4 * n);
-    memset(d_opacity, 0, sizeof(double) * n);
-    memset(d_color, 0, sizeof(double) * 3 * n);
-#pragma omp parallel
-    {
-        float *Ts = NULL, *As = NULL, *Gs = NULL;
-        size_t cap = 0;
-#pragma omp for schedule(dynamic, 1)
-        for (int64_t t = 0; t < T; ++t) {
-            int xi = (int)(t / nbh), yi = (int)(t - (int64_t)xi * nbh);
-            int left = xi * L, top = yi * L;
-            int right = left + L < W ? left + L : W, bottom = top + L < H ? top + L : H;
-            int64_t b = tile_offsets[t], e = tile_offsets[t + 1];
-            int64_t len = e - b;
-            if (len == 0) continue;
-            if ((size_t)len > cap) {
-                cap = (size_t)len;
-                Ts = (float *)realloc(Ts, cap * sizeof(float));
-                As = (float *)realloc(As, cap * sizeof(float));
-                Gs = (float *)realloc(Gs, cap * sizeof(float));
-            }
-            double *acc = (double *)calloc((size_t)len * 10, sizeof(double));
-            for (int px = left; px < right; ++px)
-                for (int py = top; py < bottom; ++py) {
-                    const float *go = dimg + ((size_t)px * H + py) * 3;
-                    float Tr = 1.0f;
-                    for (int64_t k = 0; k < len; ++k) {
-                        int g = tile_lists[b + k];
-                        float dx = pos2d[3 * g] - (float)px, dy = pos2d[3 * g + 1] - (float)py;
-                        const float *q = conic + 4 * g;
-                        float ex = (dx * q[0] + dy * q[2]) * dx + (dx * q[1] + dy * q[3]) * dy;
-                        float G = expf(-0.5f * ex);
-                        float a = opacity[g] * G;
-                        a = a < 0.01f ? 0.01f : (a > 0.99f ? 0.99f : a);
-                        Ts[k] = Tr; As[k] = a; Gs[k] = G;
-                        Tr = Tr * (1.0f - a);
-                    }
-                    /* suffix = sum_{j>k} a_j T_j (c_j . g) */
-                    float suffix = 0.0f;
-                    for (int64_t k = len - 1; k >= 0; --k) {
-                        int g = tile_lists[b + k];
-                        float a = As[k], Tk = Ts[k], G = Gs[k];
-                        const float *c = color + 3 * g;
-                        float cg_dot = c[0] * go[0] + c[1] * go[1] + c[2] * go[2];
-                        float wgt = a * Tk;
-                        double *A = acc + 10 * k;
-                        A[7] += (double)(wgt * go[0]); A[8] += (double)(wgt * go[1]); A[9] += (double)(wgt * go[2]);
-                        float d_a = Tk * cg_dot - suffix / (1.0f - a);
-                        suffix += wgt * cg_dot;
-                        float raw = opacity[g] * G;
-                        if (!(raw >= 0.01f && raw <= 0.99f)) continue;
-                        A[6] += (double)(d_a * G);                 /* d opacity */
-                        float d_G = d_a * opacity[g];
-                        float d_ex = -0.5f * G * d_G;
-                        float dx = pos2d[3 * g] - (float)px, dy = pos2d[3 * g + 1] - (float)py;
-                        const float *q = conic + 4 * g;
-                        A[2] += (double)(d_ex * dx * dx); A[3] += (double)(d_ex * dx * dy);
-                        A[4] += (double)(d_ex * dy * dx); A[5] += (double)(d_ex * dy * dy);
-                        A[0] += (double)(d_ex * (2.0f * q[0] * dx + (q[1] + q[2]) * dy));
-                        A[1] += (double)(d_ex * ((q[1] + q[2]) * dx + 2.0f * q[3] * dy));
-                    }
-                }
-            for (int64_t k = 0; k < len; ++k) {
-                int g = tile_lists[b + k];
-                const double *A = acc + 10 * k;
-#pragma omp atomic
-                d_pos2d[2 * g] += A[0];
-#pragma omp atomic
-                d_pos2d[2 * g + 1] += A[1];
-                for (int j = 0; j < 4; ++j) {
-#pragma omp atomic
-                    d_conic[4 * g + j] += A[2 + j];
-                }
-#pragma omp atomic
-                d_opacity[g] += A[6];
-                for (int j = 0; j < 3; ++j) {
-#pragma omp atomic
-                    d_color[3 * g + j] += A[7 + j];
-                }
-            }
-            free(acc);
-        }
-        free(Ts); free(As); free(Gs);
-    }
-    return GSO_OK;
+    return precise ? gso_composite_bwd_f64(v, tile_offsets, tile_lists, pos2d, conic, opacity, color, dimg,
+                                           d_pos2d, d_conic, d_opacity, d_color)
+                   : gso_composite_bwd_f32(v, tile_offsets, tile_lists, pos2d, conic, opacity, color, dimg,
+                                           d_pos2d, d_conic, d_opacity, d_color);
 }
 
 /*

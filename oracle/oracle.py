@@ -20,8 +20,8 @@ class GsoView(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "gso_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("gso_oracle.c", "gso_composite.inc")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libgso_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -63,7 +63,7 @@ class SingularCovariance(RuntimeError):
 
 
 def render(coords, scale, rotation, opacity, sh, sh_degree, width, height, tile_length,
-           w2m, proj, cam_pos, screen_coords=None, dimg=None, want_lists=True, threads=None):
+           w2m, proj, cam_pos, screen_coords=None, dimg=None, want_lists=True, threads=None, precise=False):
     """Forward (and backward when ``dimg`` is given) of the whole path on the CPU.
 
     Inputs are the raw parameters ([N,3],[N,3],[N,4],[N,1] or [N],[N,3,16]).  Returns a dict
@@ -108,7 +108,7 @@ def render(coords, scale, rotation, opacity, sh, sh_degree, width, height, tile_
     lists = lists[:total]
     out.update(tile_offsets=offsets, tile_lists=lists, num_pairs=total)
     img = np.zeros((width, height, 3), np.float32)
-    L.gso_composite_fwd(C.byref(v), _p(offsets), _p(lists), _p(pos2d), _p(conic), _p(opac), _p(color), _p(img))
+    L.gso_composite_fwd(C.byref(v), _p(offsets), _p(lists), _p(pos2d), _p(conic), _p(opac), _p(color), _p(img), int(precise))
     out["img"] = img
     if dimg is not None:
         dimg = _f32(dimg)
@@ -118,7 +118,7 @@ def render(coords, scale, rotation, opacity, sh, sh_degree, width, height, tile_
         d_opac = np.zeros(n, np.float64)
         d_color = np.zeros((n, 3), np.float64)
         L.gso_composite_bwd(C.byref(v), _p(offsets), _p(lists), _p(pos2d), _p(conic), _p(opac), _p(color),
-                            _p(dimg), _p(d_pos2d), _p(d_conic), _p(d_opac), _p(d_color))
+                            _p(dimg), _p(d_pos2d), _p(d_conic), _p(d_opac), _p(d_color), int(precise))
         g_coords = np.zeros((n, 3), np.float32)
         g_scale = np.zeros((n, 3), np.float32)
         g_rot = np.zeros((n, 4), np.float32)
@@ -134,13 +134,13 @@ def render(coords, scale, rotation, opacity, sh, sh_degree, width, height, tile_
     return out
 
 
-def render_scene(scene, tile_length, dimg=None, threads=None, screen_coords=None):
+def render_scene(scene, tile_length, dimg=None, threads=None, screen_coords=None, precise=False):
     """``render`` on a ``gsplat_amd.scenes.Scene`` (camera built on the host)."""
     cam = scene.camera(device="cpu")
     return render(scene.coords.numpy(), scene.scale.numpy(), scene.rotation.numpy(),
                   scene.opacity.numpy(), scene.sh.numpy(), scene.sh_degree, scene.width, scene.height,
                   tile_length, cam.w2m_host, cam.proj_host, np.asarray(scene.cam_position, np.float32),
-                  screen_coords=screen_coords, dimg=dimg, threads=threads)
+                  screen_coords=screen_coords, dimg=dimg, threads=threads, precise=precise)
 
 
 def max_threads() -> int:

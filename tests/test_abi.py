@@ -1,0 +1,64 @@
+"""CPU-only checks of the C-ABI boundary: the shared library loads and exports every function that
+include/gsr.h declares (no kernel is launched here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for n in ("gsr_preprocess_fwd", "gsr_preprocess_bwd", "gsr_sort_pairs", "gsr_bin_offsets", "gsr_bin_lists",
+              "gsr_composite_fwd", "gsr_composite_bwd", "gsr_exclusive_scan", "gsr_last_error"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"libgsr.so does not export {name}"
+    assert set(declared_functions()) == set(_lib.SYMBOLS)
+    assert _lib.load().gsr_version() >= 1
+
+
+def test_struct_layout_matches_header():
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd import _lib
+    # 5 x int32 + 16 + 16 + 3 floats, no padding
+    assert ctypes.sizeof(_lib.GsrView) == 4 * (5 + 16 + 16 + 3)
+
+
+def test_workspace_queries_do_not_need_a_gpu():
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd import _lib
+    lib = _lib.load()
+    assert lib.gsr_sort_workspace_bytes(0) > 0
+    assert lib.gsr_sort_workspace_bytes(1 << 20) >= (1 << 20) // 4096 * 256 * 4
+    assert lib.gsr_bin_lists_workspace_bytes(1000) >= 5 * 1000 * 4
+    assert lib.gsr_bin_offsets_workspace_bytes(1000) >= 3 * 1000 * 4
+
+
+def test_renderer_refuses_cpu_tensors():
+    """The product path has no CPU fallback: it fails loudly instead."""
+    import torch
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.model import GaussianParams
+    from gsplat_amd.renderer import GaussianRenderer
+    from gsplat_amd.scenes import synthetic_scene
+    sc = synthetic_scene(16, 32, 32, 0, 0)
+    r = GaussianRenderer(GaussianParams.from_scene(sc, "cpu"))
+    with pytest.raises(RuntimeError):
+        r.render(sc.camera(device="cpu"), 16)

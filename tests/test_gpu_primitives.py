@@ -1,0 +1,58 @@
+"""GPU tests of the scan and radix-sort entry points (bit-exact against numpy)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd import _lib
+    return _lib, _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 2048, 2049, 100_000, 3_000_001])
+def test_exclusive_scan(n):
+    L, lib = _lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 1000, size=n, dtype=np.int64).astype(np.int32)
+    tin = torch.from_numpy(x).to(dev)
+    tout = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    total = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    wsb = int(lib.gsr_scan_workspace_bytes(n))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    L.check(lib.gsr_exclusive_scan(tin.data_ptr() if n else None, tout.data_ptr(), n, total.data_ptr(), ws.data_ptr(),
+                                   wsb, _stream()), "scan")
+    ref = np.concatenate([[0], np.cumsum(x.astype(np.int64))])
+    assert int(total.cpu()[0]) == int(ref[-1])
+    if n:
+        assert np.array_equal(tout.cpu().numpy()[:n].astype(np.int64), ref[:-1])
+
+
+@pytest.mark.parametrize("n,bits,distinct", [(0, 32, 10), (1, 32, 10), (4095, 32, 1 << 30), (4096, 13, 8160),
+                                             (4097, 32, 50), (1_000_003, 32, 1 << 31), (2_500_000, 15, 32400),
+                                             (300_000, 0, 5), (70_000, 9, 400)])
+def test_sort_pairs_is_a_stable_radix_sort(n, bits, distinct):
+    L, lib = _lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, distinct, size=n, dtype=np.int64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    tk = torch.from_numpy(keys.view(np.int32).copy()).to(dev)
+    tv = torch.from_numpy(vals.view(np.int32).copy()).to(dev)
+    ko = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    vo = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    wsb = int(lib.gsr_sort_workspace_bytes(n))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    L.check(lib.gsr_sort_pairs(tk.data_ptr(), tv.data_ptr(), ko.data_ptr(), vo.data_ptr(), n, 0, bits, ws.data_ptr(),
+                               wsb, _stream()), "sort")
+    masked = keys & np.uint32((1 << bits) - 1 if bits < 32 else 0xFFFFFFFF)
+    order = np.argsort(masked, kind="stable")
+    assert np.array_equal(vo.cpu().numpy()[:n].view(np.uint32), vals[order])
+    assert np.array_equal(ko.cpu().numpy()[:n].view(np.uint32), keys[order])

@@ -21,7 +21,14 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
 
 
-def assert_close(got, ref, name="", rtol=RTOL, atol_frac=ATOL_FRAC):
+def assert_close(got, ref, name="", rtol=RTOL, atol_frac=ATOL_FRAC, outlier_frac=0.0, outlier_factor=1.0):
+    """|got - ref| <= rtol*|ref| + atol_frac*max|ref| for every element.
+
+    ``outlier_frac`` > 0 would let that fraction of the elements miss the bound by up to
+    ``outlier_factor``; no test uses it (the HIP path sits at the reference's own rounding-noise
+    level, about 1e-7 of max|ref|, once the backward divides the transmittance with a correctly
+    rounded quotient).
+    """
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
@@ -30,11 +37,18 @@ def assert_close(got, ref, name="", rtol=RTOL, atol_frac=ATOL_FRAC):
     tol = rtol * np.abs(ref) + atol_frac * scale
     err = np.abs(got - ref)
     bad = err > tol
-    if bad.any():
+    allowed = int(np.ceil(outlier_frac * bad.size)) if outlier_frac > 0 else 0
+    worse = err > outlier_factor * tol
+    if int(bad.sum()) > allowed or worse.any():
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(
-            f"{name}: {int(bad.sum())}/{bad.size} elements outside rtol={rtol} (+{atol_frac}*max); worst at {i}: "
+            f"{name}: {int(bad.sum())}/{bad.size} elements outside rtol={rtol} (+{atol_frac}*max), {allowed} allowed, "
+            f"{int(worse.sum())} beyond x{outlier_factor}; worst at {i}: "
             f"got {got[i]!r} ref {ref[i]!r} err {err[i]:.3e} tol {tol[i]:.3e} (max|ref|={scale:.3e})")
+
+
+# Extra keyword arguments for gradient comparisons across devices (none needed).
+GRAD_OUTLIERS = dict()
 
 
 def assert_bit_equal(got, ref, name=""):
