@@ -504,7 +504,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         *dst = o4;
     }
     put<ACC>(g_opac + i, go);
-    put<ACC>(g_screen + 3 * i, gsc[0]); put<ACC>(g_screen + 3 * i + 1, gsc[1]); put<ACC>(g_screen + 3 * i + 2, 0.0f);
+    // screen_coords is a fresh leaf of every render (GaussianRenderer.py:64): its gradient belongs to
+    // this view alone and is never accumulated
+    g_screen[3 * i] = gsc[0]; g_screen[3 * i + 1] = gsc[1]; g_screen[3 * i + 2] = 0.0f;
     float4 *dsh = reinterpret_cast<float4 *>(g_sh + (size_t)i * 48);
 #pragma unroll
     for (int c = 0; c < 3; ++c)

@@ -40,6 +40,46 @@ class SingularCovarianceError(RuntimeError):
     (``Utils/Probability.py:15``) in this situation."""
 
 
+class StageTimer:
+    """Optional per-stage device timing: HIP events recorded on the stream the kernels run on.
+
+    ``with StageTimer() as t: ...render...`` then ``t.summary()`` -> {stage: (calls, total_ms)}.
+    """
+    active = None
+
+    def __init__(self):
+        self.events = []
+
+    def __enter__(self):
+        StageTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        StageTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.events:
+            n, ms = out.get(name, (0, 0.0))
+            out[name] = (n + 1, ms + a.elapsed_time(b))
+        return out
+
+
+def _call(name, fn, *args):
+    """Invoke one C-ABI entry point; raise on a non-zero code; time it when a StageTimer is active."""
+    timer = StageTimer.active
+    if timer is None:
+        _lib.check(fn(*args), name)
+        return
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.check(fn(*args), name)
+    b.record()
+    timer.events.append((name, a, b))
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -100,16 +140,16 @@ def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, vi
     st.ntiles = torch.empty(n, **i32)
     st.rec = torch.empty(n, _lib.REC_FLOATS, **f32)
     counters = torch.zeros(8, **i32)
-    _lib.check(lib.gsr_preprocess_fwd(cv, _ptr(coords), _ptr(scale_raw), _ptr(rot_raw), _ptr(opac_raw), _ptr(sh),
+    _call("gsr_preprocess_fwd", lib.gsr_preprocess_fwd, cv, _ptr(coords), _ptr(scale_raw), _ptr(rot_raw), _ptr(opac_raw), _ptr(sh),
                                       _ptr(screen_coords), _ptr(st.mask_u8), _ptr(depth_key), _ptr(st.pos2d),
                                       _ptr(st.cov2d), _ptr(st.radius_full), _ptr(st.bbox), _ptr(st.ntiles),
-                                      _ptr(st.rec), _ptr(counters), stream), "gsr_preprocess_fwd")
+                                      _ptr(st.rec), _ptr(counters), stream)
     st.order = torch.empty(n, **i32)
     st.slot_base = torch.empty(n, **i32)
     ws_bytes = int(lib.gsr_bin_offsets_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.check(lib.gsr_bin_offsets(_ptr(depth_key), _ptr(st.ntiles), n, _ptr(st.order), _ptr(st.slot_base),
-                                   _ptr(counters), _ptr(ws), ws_bytes, stream), "gsr_bin_offsets")
+    _call("gsr_bin_offsets", lib.gsr_bin_offsets, _ptr(depth_key), _ptr(st.ntiles), n, _ptr(st.order), _ptr(st.slot_base),
+                                   _ptr(counters), _ptr(ws), ws_bytes, stream)
     host = counters.cpu()          # the one synchronisation of the forward
     st.num_visible, st.num_pairs, err = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2])
     if err & 1:
@@ -124,20 +164,22 @@ def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, vi
     st.stream_rec = torch.empty(max(I, 1), _lib.REC_FLOATS, **f32)
     ws_bytes = int(lib.gsr_bin_lists_workspace_bytes(I))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.check(lib.gsr_bin_lists(cv, _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
+    _call("gsr_bin_lists", lib.gsr_bin_lists, cv, _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
                                  _ptr(st.tile_offsets), _ptr(st.pair_pos), _ptr(st.sorted_gauss),
-                                 _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream), "gsr_bin_lists")
+                                 _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream)
     st.img = torch.empty(view.width, view.height, 3, **f32)
     st.final_T = torch.empty(view.width, view.height, **f32)
-    _lib.check(lib.gsr_composite_fwd(cv, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.img), _ptr(st.final_T),
-                                     stream), "gsr_composite_fwd")
+    _call("gsr_composite_fwd", lib.gsr_composite_fwd, cv, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.img), _ptr(st.final_T),
+          stream)
     return st
 
 
-def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh, dimg, accumulate_into=None):
+def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh, dimg, accumulate_into=None,
+                      overwrite=False):
     """Compositing backward + stage-1 backward.  Returns the six dense gradients
     (coords, scale, rotation, opacity[N,1], sh, screen_coords).  ``accumulate_into`` may hold six
-    existing buffers to add to (view minibatches)."""
+    existing buffers to add to (view minibatches); with ``overwrite`` they are written instead (the
+    first view of a minibatch).  The screen_coords gradient is always overwritten."""
     lib = _lib.load()
     dev = coords.device
     n = st.n
@@ -146,21 +188,21 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
     pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
-    _lib.check(lib.gsr_composite_bwd(st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.final_T),
-                                     _ptr(dimg), I, _ptr(pairgrad), stream), "gsr_composite_bwd")
+    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.final_T),
+                                     _ptr(dimg), I, _ptr(pairgrad), stream)
     st.pairgrad = pairgrad
     if accumulate_into is None:
         grads = (torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32),
                  torch.empty(n, 1, **f32), torch.empty(n, 3, 16, **f32), torch.empty(n, 3, **f32))
         acc = 0
     else:
-        grads, acc = accumulate_into, 1
+        grads, acc = accumulate_into, (0 if overwrite else 1)
     if opac_raw.dim() == 1:
         opac_raw = opac_raw.unsqueeze(1)
-    _lib.check(lib.gsr_preprocess_bwd(st.cview, _ptr(coords.contiguous()), _ptr(scale_raw.contiguous()),
+    _call("gsr_preprocess_bwd", lib.gsr_preprocess_bwd, st.cview, _ptr(coords.contiguous()), _ptr(scale_raw.contiguous()),
                                       _ptr(rot_raw.contiguous()), _ptr(opac_raw.contiguous()), _ptr(sh.contiguous()),
                                       _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(st.pair_pos),
-                                      _ptr(pairgrad), *[_ptr(g) for g in grads], acc, stream), "gsr_preprocess_bwd")
+                                      _ptr(pairgrad), *[_ptr(g) for g in grads], acc, stream)
     return grads
 
 

@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fwd+bwd renders/s at 1 M Gaussians, 1920x1080, 8-view minibatch.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one view minibatch: every view is rendered forward and
+backward (all five parameter gradients + the screen_coords gradient), the parameter gradients of
+the rank's views are accumulated in one flat bucket, and with N > 1 ranks the bucket is summed
+over ranks with one RCCL all-reduce.  The 8 views of the minibatch are split contiguously over the
+ranks (strong scaling: the minibatch is fixed, as BASELINE.json's config 3 states it).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import gsplat_amd  # noqa: E402,F401
+from gsplat_amd.camera import Camera  # noqa: E402
+from gsplat_amd.rasterizer import StageTimer, ViewSpec, backward_pipeline, forward_pipeline  # noqa: E402
+from gsplat_amd.scenes import synthetic_scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector fp32 spec
+
+
+def minibatch_cameras(scene, n_views, device):
+    """Cameras of one view minibatch: a ring of radius 0.15 around the scene's base pose, all
+    looking down -z.  Every view sees (almost) the whole cloud, so the per-view work is uniform."""
+    cams = []
+    for v in range(n_views):
+        ang = 2.0 * np.pi * v / n_views
+        pos = np.array([0.15 * np.cos(ang), 0.15 * np.sin(ang), 0.0])
+        cams.append(Camera(pos, np.array([1.0, 0.0, 0.0, 0.0]), scene.fx, scene.fy, scene.width / 2,
+                           scene.height / 2, scene.width, scene.height, device=device))
+    return cams
+
+
+def algorithmic_bytes(n, m, pairs, pixels, k_sh):
+    """Compulsory HBM bytes per view of each stage (formulas stated in DESIGN.md)."""
+    return {
+        "preprocess_fwd": n * (12 + 12 + 16 + 4 + 12 * k_sh) + n + m * 64,
+        "binning_sort": m * 16 + pairs * 12 + 2 * pairs * 12 + pairs * 8,
+        "composite_fwd": pairs * (4 + 40) + pixels * 12 + pixels * 4,
+        "composite_bwd": pairs * 44 + pixels * (12 + 12 + 8) + m * 40,
+        "preprocess_bwd": m * 40 + n * (44 + 12 * k_sh) + n * (44 + 192) + n * 12,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--tile", type=int, default=16)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the render path has no CPU implementation)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.views % world != 0:
+        raise SystemExit(f"--views {args.views} must be a multiple of the number of ranks {world}")
+
+    n = args.gaussians
+    scene = synthetic_scene(n, args.width, args.height, args.sh_degree, seed=0)
+    params = [t.to(dev) for t in scene.params()]
+    cams = minibatch_cameras(scene, args.views, dev)
+    per_rank = args.views // world
+    my_views = list(range(rank * per_rank, (rank + 1) * per_rank))
+    views = [ViewSpec.from_camera(cams[v], args.sh_degree, args.tile) for v in my_views]
+    gen = torch.Generator().manual_seed(1)
+    # dL/dimg of loss = mean over the minibatch of sum(img * R_v)
+    cots = [(torch.rand(args.width, args.height, 3, generator=gen) / args.views).to(dev) for _ in range(args.views)]
+    cots = [cots[v] for v in my_views]
+
+    # one flat fp32 bucket for the five parameter gradients (59 floats per Gaussian)
+    sizes = [3, 3, 4, 1, 48]
+    bucket = torch.zeros(n * sum(sizes), dtype=torch.float32, device=dev)
+    grads, off = [], 0
+    for s_ in sizes:
+        grads.append(bucket[off:off + n * s_].view(n, s_) if s_ != 48 else bucket[off:off + n * s_].view(n, 3, 16))
+        off += n * s_
+    g_screen = torch.empty(n, 3, dtype=torch.float32, device=dev)
+
+    stats = {}
+
+    def step():
+        for i, (view, cot) in enumerate(zip(views, cots)):
+            st = forward_pipeline(*params, None, view)
+            if st.num_visible == 0:
+                continue
+            if i == 0:
+                stats.update(m=st.num_visible, pairs=st.num_pairs)
+            acc = tuple(grads) + (g_screen,)
+            if i == 0:
+                # first view of the step overwrites the bucket, the rest accumulate
+                backward_pipeline(st, *params, cot, accumulate_into=acc, overwrite=True)
+            else:
+                backward_pipeline(st, *params, cot, accumulate_into=acc)
+        if world > 1:
+            dist.all_reduce(bucket)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    with StageTimer() as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+    stage = timer.summary()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        renders = args.views * args.steps
+        value = renders / elapsed
+        pixels = args.width * args.height
+        k_sh = (args.sh_degree + 1) ** 2
+        ab = algorithmic_bytes(n, stats.get("m", n), stats.get("pairs", 0), pixels, k_sh)
+        stage_ms = {k.replace("gsr_", ""): (v[1] / v[0]) for k, v in stage.items()}
+        dom = "composite_bwd"
+        dom_ms = stage_ms.get(dom, float("nan"))
+        achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            key = f"{n}_{args.width}x{args.height}_t{args.tile}_deg{args.sh_degree}"
+            traffic = tj.get(key, {}).get(dom)
+        pairs = stats.get("pairs", 0)
+        flops_bwd = 60.0 * pairs * 256.0 if args.tile == 16 else None
+        out = {
+            "metric": "fwd+bwd renders/sec @1M Gaussians 1080p, 1/2/4/8 GPUs; % HBM roofline",
+            "value": round(value, 3),
+            "unit": "renders/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n} synthetic Gaussians, SH degree {args.sh_degree}, {args.width}x{args.height}, "
+                            f"tile {args.tile}, {args.views}-view minibatch fwd+bwd split over {world} GPU(s), "
+                            + ("RCCL all-reduce of the 59N-float gradient bucket" if world > 1 else "no collective"),
+                "gaussians": n, "width": args.width, "height": args.height, "tile_length": args.tile,
+                "sh_degree": args.sh_degree, "views_per_step": args.views,
+                "visible": stats.get("m"), "pairs_per_view": pairs,
+            },
+            "roofline": {
+                "kernel": "composite_bwd_kernel", "bound": "hbm",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": round(dom_ms, 4),
+                "note": "compositing is FP32-VALU/transcendental bound at these list lengths, not HBM bound",
+            },
+            "stage_ms_per_view": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_hbm_frac": {k: round(ab[a] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                               for k, a in (("preprocess_fwd", "preprocess_fwd"), ("composite_fwd", "composite_fwd"),
+                                            ("composite_bwd", "composite_bwd"), ("preprocess_bwd", "preprocess_bwd"))
+                               if k in stage_ms},
+        }
+        if flops_bwd:
+            out["roofline"]["valu_frac_algorithmic"] = round(flops_bwd / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, cams[0], args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, cam, args):
+    """The CPU port (oracle/) on this host's cores: one view of the minibatch, forward + backward."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    threads = min(oracle.max_threads(), 16)
+    cot = np.full((args.width, args.height, 3), 1.0 / args.views, np.float32)
+    p = [t.numpy() for t in scene.params()]
+    t0 = time.perf_counter()
+    oracle.render(p[0], p[1], p[2], p[3], p[4], args.sh_degree, args.width, args.height, args.tile,
+                  cam.w2m_host, cam.proj_host, np.asarray(cam.transform.position, np.float32), dimg=cot, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "renders/s", "cores": threads, "kind": "port",
+            "sample": f"1 of the {args.views} views, forward + backward, same scene and tile size ({dt:.1f} s)"}
+
+
+if __name__ == "__main__":
+    main()

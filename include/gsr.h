@@ -84,9 +84,10 @@ int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const flo
  * pair's position in the sorted stream; Gaussian g owns emission slots slot_base[g] ..
  * slot_base[g]+ntiles[g], and pair_pos[e] maps slot e to its position.  A Gaussian's records
  * are summed in slot order, so the result is reproducible run to run.
- * Writes (or, with accumulate != 0, adds to) the dense gradients of the raw parameters:
- * g_coords[N,3] g_scale[N,3] g_rot[N,4] g_opac[N] g_sh[N,3,16] g_screen[N,3]
- * (g_sh beyond the active degree, g_screen[:,2] and the rows of culled Gaussians are 0). */
+ * Writes (or, with accumulate != 0, adds to) the dense gradients of the raw parameters
+ * g_coords[N,3] g_scale[N,3] g_rot[N,4] g_opac[N] g_sh[N,3,16], and always overwrites
+ * g_screen[N,3] (the gradient of this view's screen_coords leaf).  g_sh beyond the active degree,
+ * g_screen[:,2] and the rows of culled Gaussians are 0. */
 int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
                        const float *rot_raw, const float *opac_raw, const float *sh,
                        const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
