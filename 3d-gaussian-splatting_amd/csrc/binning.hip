@@ -59,10 +59,44 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
         }
 }
 
+// True when alpha = clamp(opacity*G, 0.01, 0.99) is pinned at 0.01 on EVERY pixel of the tile
+// rectangle [x0,x1] x [y0,y1] (inclusive integer pixels), with a margin that covers the fp32
+// evaluation of the exponent in the compositing kernels.  The quadratic form is convex (checked),
+// so its minimum over the rectangle is 0 when the centre lies inside and otherwise sits on one of
+// the four edges.  The test is conservative: a pair it misses is simply evaluated in full.
+__device__ inline bool tile_all_clamped_low(float gx, float gy, float A, float B, float D, float o, float x0,
+                                            float x1, float y0, float y1)
+{
+    if (!(o > 0.0f)) return o == 0.0f;                  // opacity underflowed to 0: raw = 0 everywhere
+    // A, B, D are the exp2-domain coefficients (negative-definite for a valid Gaussian)
+    const float a = -A, bh = -0.5f * B, d = -D;          // f(dx,dy) = a dx^2 + 2 bh dx dy + d dy^2 = -log2(G)
+    if (!(a > 0.0f && d > 0.0f && a * d > 1.000001f * bh * bh)) return false;
+    const float dx0 = gx - x1, dx1 = gx - x0, dy0 = gy - y1, dy1 = gy - y0;   // d = centre - pixel
+    float fmin;
+    if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) {
+        fmin = 0.0f;
+    } else {
+        fmin = 3.0e38f;
+        const float ex[2] = {dx0, dx1}, ey[2] = {dy0, dy1};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float t = fminf(fmaxf(-bh * ex[k] / d, dy0), dy1);        // edge dx = ex[k]
+            fmin = fminf(fmin, a * ex[k] * ex[k] + 2.0f * bh * ex[k] * t + d * t * t);
+            t = fminf(fmaxf(-bh * ey[k] / a, dx0), dx1);              // edge dy = ey[k]
+            fmin = fminf(fmin, a * t * t + 2.0f * bh * t * ey[k] + d * ey[k] * ey[k]);
+        }
+    }
+    const float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1));
+    const float mag = a * mx * mx + 2.0f * fabsf(bh) * mx * my + d * my * my;   // bound on the summed terms
+    // raw < 0.01  <=>  log2(o) - f < log2(0.01); slack: rounding of f here and in the kernels
+    return __log2f(o) - fmin + 4.0e-6f * mag + 1.0e-4f < -6.6438561898f;
+}
+
 // One thread per sorted position p: copy the owner's splat record into the stream, record where
-// slot e went, and mark tile boundaries.
+// slot e went, mark tile boundaries, and flag (sign bit of the opacity) records whose alpha is
+// 0.01 on the whole tile so the compositing kernels can skip their exponentials.
 __global__ __launch_bounds__(256) void finalize_lists_kernel(
-    const uint32_t *__restrict__ sorted_tile, const uint32_t *__restrict__ sorted_slot,
+    ViewK v, const uint32_t *__restrict__ sorted_tile, const uint32_t *__restrict__ sorted_slot,
     const uint32_t *__restrict__ owner, const float *__restrict__ rec, uint32_t num_pairs, uint32_t T,
     uint32_t *__restrict__ tile_offsets, uint32_t *__restrict__ pair_pos, uint32_t *__restrict__ sorted_gauss,
     float *__restrict__ stream_rec)
@@ -76,8 +110,14 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
     const float4 *src = reinterpret_cast<const float4 *>(rec + (size_t)g * GSR_REC_FLOATS);
     float4 *dst = reinterpret_cast<float4 *>(stream_rec + (size_t)p * GSR_REC_FLOATS);
     float4 a = src[0], b = src[1], c = src[2];
-    dst[0] = a; dst[1] = b; dst[2] = c;
     const uint32_t cur = sorted_tile[p];
+    {
+        const int xi = (int)(cur / (uint32_t)v.nbh), yi = (int)(cur - (uint32_t)xi * v.nbh);
+        const float x0 = (float)(xi * v.L), y0 = (float)(yi * v.L);
+        const float x1 = (float)(min((xi + 1) * v.L, v.W) - 1), y1 = (float)(min((yi + 1) * v.L, v.H) - 1);
+        if (tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, y1)) b.y = -b.y;
+    }
+    dst[0] = a; dst[1] = b; dst[2] = c;
     const uint32_t first = p == 0 ? 0u : sorted_tile[p - 1] + 1u;
     for (uint32_t t = first; t <= cur; ++t) tile_offsets[t] = p;  // tiles (prev, cur] start at p
     if (p + 1 == num_pairs)
@@ -175,7 +215,7 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_bas
     if (int e = gsr_sort_pairs(tile_key, slot_id, sorted_tile, sorted_slot, num_pairs, 0, bits_for((uint32_t)v.T),
                                sort_ws, sort_bytes, stream))
         return e;
-    hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, sorted_tile,
+    hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v, sorted_tile,
                        sorted_slot, owner, rec, num_pairs, (uint32_t)v.T, tile_offsets, pair_pos, sorted_gauss,
                        stream_rec);
     return gsr_check_launch("bin_lists");

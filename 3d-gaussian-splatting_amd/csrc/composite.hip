@@ -53,29 +53,41 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
     return true;
 }
 
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One 48-byte splat record held in 12 SGPRs.
 struct Rec {
-    float gx, gy, A, B, D, o, r, g, b;  // centre, pre-scaled conic (exp2 domain), opacity, colour
-    float ca, cbh, cd;                  // conic a, (b+c)/2, d as they are (backward only)
+    f32x8 a;   // gx, gy, A, B, D, o, r, g   centre, pre-scaled conic (exp2 domain), opacity, red, green
+    f32x4 b;   // b, ca, cbh, cd             blue, conic a, (b+c)/2, d as they are (backward only)
 };
+#define R_gx(R) ((R).a[0])
+#define R_gy(R) ((R).a[1])
+#define R_A(R) ((R).a[2])
+#define R_B(R) ((R).a[3])
+#define R_D(R) ((R).a[4])
+#define R_o(R) ((R).a[5])
+#define R_r(R) ((R).a[6])
+#define R_g(R) ((R).a[7])
+#define R_b(R) ((R).b[0])
+#define R_ca(R) ((R).b[1])
+#define R_cbh(R) ((R).b[2])
+#define R_cd(R) ((R).b[3])
 
-__device__ inline Rec load_rec(const float *__restrict__ stream_rec, uint32_t k)
+// Scalar loads of record k, issued now and waited for later (rec_wait), so that the latency of
+// one record's fetch (a few hundred cycles from L2) overlaps the arithmetic of the previous one.
+// hipcc would otherwise sink the load below its last use to reuse the registers.  The waits are
+// written by hand because the compiler does not count loads issued from inline asm.
+__device__ inline void rec_request(const float *__restrict__ stream_rec, uint32_t k, Rec &R)
 {
     const float *p = stream_rec + (size_t)k * GSR_REC_FLOATS;
-    Rec R;
-    R.gx = p[0]; R.gy = p[1]; R.A = p[2]; R.B = p[3];
-    R.D = p[4]; R.o = p[5]; R.r = p[6]; R.g = p[7];
-    R.b = p[8];
-    R.ca = R.cbh = R.cd = 0.0f;
-    return R;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(R.a), "=&s"(R.b) : "s"(p) : "memory");
 }
+__device__ inline void rec_wait(Rec &R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b)::"memory"); }
 
-__device__ inline Rec load_rec_bwd(const float *__restrict__ stream_rec, uint32_t k)
-{
-    const float *p = stream_rec + (size_t)k * GSR_REC_FLOATS;
-    Rec R = load_rec(stream_rec, k);
-    R.ca = p[9]; R.cbh = p[10]; R.cd = p[11];
-    return R;
-}
+// The list builder sets the sign bit of the opacity when alpha is pinned at 0.01 on every pixel of
+// the tile (wave-uniform: a scalar compare and branch).
+__device__ inline bool rec_all_clamped_low(const Rec &R) { return __float_as_int(R_o(R)) < 0; }
 
 __device__ inline float clamp_alpha(float raw) { return fminf(fmaxf(raw, kAlphaMin), kAlphaMax); }
 
@@ -90,23 +102,53 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
 #pragma unroll
     for (int j = 0; j < 4; ++j) { pyf[j] = (float)(w.y0 + j); T[j] = 1.0f; cr[j] = cg[j] = cb[j] = 0.0f; }
 
-    for (uint32_t k = w.begin; k < w.end; ++k) {
-        const Rec R = load_rec(stream_rec, k);
-        const float dx = R.gx - pxf;
-        const float adx2 = R.A * dx * dx;
-        const float bdx = R.B * dx;
+    auto blend = [&](const Rec &R) {
+        if (rec_all_clamped_low(R)) {
+            // alpha is 0.01 on the whole tile: no exponent, no exp
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float wgt = kAlphaMin * T[j];
+                cr[j] = fmaf(wgt, R_r(R), cr[j]);
+                cg[j] = fmaf(wgt, R_g(R), cg[j]);
+                cb[j] = fmaf(wgt, R_b(R), cb[j]);
+                T[j] = T[j] * (1.0f - kAlphaMin);
+            }
+            return;
+        }
+        const float dx = R_gx(R) - pxf;
+        const float adx2 = R_A(R) * dx * dx;
+        const float bdx = R_B(R) * dx;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float dy = R.gy - pyf[j];
-            const float q = fmaf(fmaf(R.D, dy, bdx), dy, adx2);
+            const float dy = R_gy(R) - pyf[j];
+            const float q = fmaf(fmaf(R_D(R), dy, bdx), dy, adx2);
             const float G = __builtin_amdgcn_exp2f(q);
-            const float a = clamp_alpha(R.o * G);
+            const float a = clamp_alpha(R_o(R) * G);
             const float wgt = a * T[j];
-            cr[j] = fmaf(wgt, R.r, cr[j]);
-            cg[j] = fmaf(wgt, R.g, cg[j]);
-            cb[j] = fmaf(wgt, R.b, cb[j]);
+            cr[j] = fmaf(wgt, R_r(R), cr[j]);
+            cg[j] = fmaf(wgt, R_g(R), cg[j]);
+            cb[j] = fmaf(wgt, R_b(R), cb[j]);
             T[j] = T[j] * (1.0f - a);   // same rounding as the reference's cumprod of (1 - alpha)
         }
+    };
+    if (w.begin < w.end) {
+        // two record buffers, alternating: while one is blended the other is in flight
+        const uint32_t last = w.end - 1;
+        uint32_t k = w.begin;
+        Rec A, B;
+        rec_request(stream_rec, k, A);
+        for (;;) {
+            rec_wait(A);
+            rec_request(stream_rec, min(k + 1, last), B);
+            blend(A);
+            if (++k >= w.end) break;
+            rec_wait(B);
+            rec_request(stream_rec, min(k + 1, last), A);
+            blend(B);
+            if (++k >= w.end) break;
+        }
+        rec_wait(A);   // nothing may be in flight when the wave ends
+        rec_wait(B);
     }
     if (!w.vx) return;
 #pragma unroll
@@ -129,15 +171,52 @@ __device__ inline float dpp_add(float val)
     return val + __int_as_float(moved);
 }
 
-__device__ inline float wave_sum_to_lane63(float x)
+// Row-broadcast steps of the wave reduction.  hipcc fuses a DPP move into a float add only for full
+// row masks, so these two steps are written as the single instruction they are.  DPP reads need two
+// wait states after the VALU write of their source: one s_nop 1 ahead of each group; inside a
+// group consecutive instructions touch different registers.
+#define GSR_BCAST3(ctrl, mask, x)                                                                           \
+    asm volatile("s_nop 1\n\t"                                                                             \
+                 "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
+                 "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
+                 "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:" mask " bank_mask:0xf"                         \
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]))
+
+// Sums 3*G values (G groups of three) over the 64 lanes; totals land in lane 63.  Each DPP step is
+// applied to all values before the next step starts, so dependent steps are far enough apart.
+template <int N>
+__device__ inline void wave_sum_to_lane63(float (&x)[N])
 {
-    x = dpp_add<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
-    x = dpp_add<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
-    x = dpp_add<0x141, 0xF>(x);  // row_half_mirror
-    x = dpp_add<0x140, 0xF>(x);  // row_mirror: every lane of a 16-lane row holds the row sum
-    x = dpp_add<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
-    x = dpp_add<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
-    return x;
+    static_assert(N % 3 == 0, "values are reduced in groups of three");
+#pragma unroll
+    for (int c = 0; c < N; ++c) x[c] = dpp_add<0xB1, 0xF>(x[c]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int c = 0; c < N; ++c) x[c] = dpp_add<0x4E, 0xF>(x[c]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int c = 0; c < N; ++c) x[c] = dpp_add<0x141, 0xF>(x[c]);  // row_half_mirror
+#pragma unroll
+    for (int c = 0; c < N; ++c) x[c] = dpp_add<0x140, 0xF>(x[c]);  // row_mirror: every lane holds its row's sum
+#pragma unroll
+    for (int c = 0; c < N; c += 3) { float (&g)[3] = reinterpret_cast<float (&)[3]>(x[c]); GSR_BCAST3("row_bcast:15", "0xa", g); }
+#pragma unroll
+    for (int c = 0; c < N; c += 3) { float (&g)[3] = reinterpret_cast<float (&)[3]>(x[c]); GSR_BCAST3("row_bcast:31", "0xc", g); }
+}
+
+// One gradient record: plain stores when a single wave owns the tile, float atomics otherwise.
+template <bool ATOMIC>
+__device__ inline void store_pairgrad(float *dst, float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                      float v7, float v8)
+{
+    if (ATOMIC) {
+        const float v[9] = {v0, v1, v2, v3, v4, v5, v6, v7, v8};
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+            if (v[c] != 0.0f) atomicAdd(dst + c, v[c]);
+    } else {
+        reinterpret_cast<float4 *>(dst)[0] = make_float4(v0, v1, v2, v3);
+        reinterpret_cast<float4 *>(dst)[1] = make_float4(v4, v5, v6, v7);
+        reinterpret_cast<float4 *>(dst)[2] = make_float4(v8, 0.0f, 0.0f, 0.0f);
+    }
 }
 
 // Reverse sweep of one list for the 4 pixels of a lane.  CHECK: pixel j only takes part in
@@ -149,21 +228,49 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
 {
     float suffix[4] = {0.f, 0.f, 0.f, 0.f};
     const int lane = threadIdx.x & 63;
-    for (uint32_t k = w.end; k-- > w.begin;) {
-        const Rec R = load_rec_bwd(stream_rec, k);
-        const float dx = R.gx - pxf;
-        const float adx2 = R.A * dx * dx;
-        const float bdx = R.B * dx;
-        const float cadx = R.ca * dx;    // with v = conic * d:  v_x = a dx + bh dy,  v_y = bh dx + d dy
-        const float cbdx = R.cbh * dx;
+    auto entry = [&](const Rec &R, uint32_t k) {
+        float *dst = pairgrad + (size_t)k * GSR_PAIRGRAD_FLOATS;
+        if (rec_all_clamped_low(R)) {
+            // alpha = 0.01 on every pixel: only the transmittance recurrence, the colour sums and the
+            // suffix remain; the clamp blocks every geometric gradient
+            const float om = 1.0f - kAlphaMin, rcp = 1.0f / (1.0f - kAlphaMin);
+            float col[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t0 = T[j] * rcp;
+                float Tk = fmaf(fmaf(-om, t0, T[j]), rcp, t0);
+                float wgt = kAlphaMin * Tk;
+                const float cgd = fmaf(R_b(R), gb[j], fmaf(R_g(R), gg[j], R_r(R) * gr[j]));
+                float suf = fmaf(wgt, cgd, suffix[j]);
+                if (CHECK) {
+                    const bool on = (k - w.begin) < nstop[j];
+                    Tk = on ? Tk : T[j];
+                    suf = on ? suf : suffix[j];
+                    wgt = on ? wgt : 0.0f;
+                }
+                T[j] = Tk;
+                suffix[j] = suf;
+                col[0] = fmaf(wgt, gr[j], col[0]);
+                col[1] = fmaf(wgt, gg[j], col[1]);
+                col[2] = fmaf(wgt, gb[j], col[2]);
+            }
+            wave_sum_to_lane63(col);
+            if (lane == 63) store_pairgrad<ATOMIC>(dst, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, col[0], col[1], col[2]);
+            return;
+        }
+        const float dx = R_gx(R) - pxf;
+        const float adx2 = R_A(R) * dx * dx;
+        const float bdx = R_B(R) * dx;
+        const float cadx = R_ca(R) * dx;   // with v = conic * d:  v_x = a dx + bh dy,  v_y = bh dx + d dy
+        const float cbdx = R_cbh(R) * dx;
         float s_vx = 0.f, s_vy = 0.f, s_xx = 0.f, s_xy = 0.f, s_yy = 0.f, s_o = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
         bool any_pass = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float dy = R.gy - pyf[j];
-            const float q = fmaf(fmaf(R.D, dy, bdx), dy, adx2);
+            const float dy = R_gy(R) - pyf[j];
+            const float q = fmaf(fmaf(R_D(R), dy, bdx), dy, adx2);
             const float G = __builtin_amdgcn_exp2f(q);
-            const float raw = R.o * G;
+            const float raw = R_o(R) * G;
             const float a = clamp_alpha(raw);
             // T_k = T_{k+1} / (1 - a), correctly rounded: quotient estimate, exact remainder (fma), one
             // correction.  A plain T * rcp(1 - a) is not good enough here: most entries of a long list
@@ -174,7 +281,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             const float t0 = T[j] * rcp;
             float Tk = fmaf(fmaf(-om, t0, T[j]), rcp, t0);   // transmittance in front of this entry
             float wgt = a * Tk;
-            const float cgd = fmaf(R.b, gb[j], fmaf(R.g, gg[j], R.r * gr[j]));
+            const float cgd = fmaf(R_b(R), gb[j], fmaf(R_g(R), gg[j], R_r(R) * gr[j]));
             float d_a = fmaf(Tk, cgd, -(suffix[j] * rcp));
             float suf = fmaf(wgt, cgd, suffix[j]);
             if (CHECK) {
@@ -196,8 +303,8 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             const float h = d_raw * a;                     // = -2 dL/d(exponent); a == raw when it matters
             // Sums are taken in the conic-weighted coordinates v: summing h*d and weighting by the
             // conic afterwards would cancel large coherent sums for elongated Gaussians.
-            const float vx = fmaf(R.cbh, dy, cadx);
-            const float vy = fmaf(R.cd, dy, cbdx);
+            const float vx = fmaf(R_cbh(R), dy, cadx);
+            const float vy = fmaf(R_cd(R), dy, cbdx);
             const float hvx = h * vx, hvy = h * vy;
             s_vx += hvx;
             s_vy += hvy;
@@ -205,30 +312,36 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             s_xy = fmaf(hvx, vy, s_xy);
             s_yy = fmaf(hvy, vy, s_yy);
         }
-        float val[9] = {s_vx, s_vy, s_xx, s_xy, s_yy, s_o, s_r, s_g, s_b};
         const bool any_geom = __ballot(any_pass) != 0ull;
-        float *dst = pairgrad + (size_t)k * GSR_PAIRGRAD_FLOATS;
         if (any_geom) {
-#pragma unroll
-            for (int c = 0; c < 9; ++c) val[c] = wave_sum_to_lane63(val[c]);
+            float val[9] = {s_vx, s_vy, s_xx, s_xy, s_yy, s_o, s_r, s_g, s_b};
+            wave_sum_to_lane63(val);
+            if (lane == 63)
+                store_pairgrad<ATOMIC>(dst, val[0], val[1], val[2], val[3], val[4], val[5], val[6], val[7], val[8]);
         } else {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) val[c] = 0.0f;
-#pragma unroll
-            for (int c = 6; c < 9; ++c) val[c] = wave_sum_to_lane63(val[c]);
+            float col[3] = {s_r, s_g, s_b};
+            wave_sum_to_lane63(col);
+            if (lane == 63) store_pairgrad<ATOMIC>(dst, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, col[0], col[1], col[2]);
         }
-        if (lane == 63) {
-            if (ATOMIC) {
-#pragma unroll
-                for (int c = 0; c < 9; ++c)
-                    if (val[c] != 0.0f) atomicAdd(dst + c, val[c]);
-            } else {
-                reinterpret_cast<float4 *>(dst)[0] = make_float4(val[0], val[1], val[2], val[3]);
-                reinterpret_cast<float4 *>(dst)[1] = make_float4(val[4], val[5], val[6], val[7]);
-                reinterpret_cast<float4 *>(dst)[2] = make_float4(val[8], 0.0f, 0.0f, 0.0f);
-            }
-        }
+    };
+    // back to front, two record buffers alternating (see composite_fwd_kernel)
+    uint32_t k = w.end - 1;   // the caller guarantees a non-empty list
+    Rec A, B;
+    rec_request(stream_rec, k, A);
+    for (;;) {
+        rec_wait(A);
+        rec_request(stream_rec, k > w.begin ? k - 1 : k, B);
+        entry(A, k);
+        if (k == w.begin) break;
+        --k;
+        rec_wait(B);
+        rec_request(stream_rec, k > w.begin ? k - 1 : k, A);
+        entry(B, k);
+        if (k == w.begin) break;
+        --k;
     }
+    rec_wait(A);
+    rec_wait(B);
 }
 
 // ATOMIC = several waves share a tile (L > 16): their sums meet in pairgrad through float atomics
@@ -269,15 +382,18 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Tf[j] = 1.0f; Ts[j] = 0.0f; nstop[j] = len; }
         for (uint32_t k = w.begin; k < w.end; ++k) {
-            const Rec R = load_rec(stream_rec, k);
-            const float dx = R.gx - pxf;
-            const float adx2 = R.A * dx * dx;
-            const float bdx = R.B * dx;
+            Rec R;
+            rec_request(stream_rec, k, R);
+            rec_wait(R);
+            const bool low = rec_all_clamped_low(R);
+            const float dx = R_gx(R) - pxf;
+            const float adx2 = R_A(R) * dx * dx;
+            const float bdx = R_B(R) * dx;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float dy = R.gy - pyf[j];
-                const float q = fmaf(fmaf(R.D, dy, bdx), dy, adx2);
-                const float a = clamp_alpha(R.o * __builtin_amdgcn_exp2f(q));
+                const float dy = R_gy(R) - pyf[j];
+                const float q = fmaf(fmaf(R_D(R), dy, bdx), dy, adx2);
+                const float a = low ? kAlphaMin : clamp_alpha(R_o(R) * __builtin_amdgcn_exp2f(q));
                 Tf[j] = Tf[j] * (1.0f - a);
                 const bool hit = (Tf[j] < kTinyT) && (nstop[j] == len);
                 nstop[j] = hit ? (k - w.begin + 1u) : nstop[j];
