@@ -91,6 +91,15 @@ __device__ inline bool rec_all_clamped_low(const Rec &R) { return __float_as_int
 
 __device__ inline float clamp_alpha(float raw) { return fminf(fmaxf(raw, kAlphaMin), kAlphaMax); }
 
+// Two pixels per operation.  On gfx950 a v_fma_f32 costs about 4.4 cycles of a SIMD and a
+// v_pk_fma_f32 about 5.6 for two lanes' worth (measured, tools/ubench/valu_rate.hip), so the
+// per-pixel fused multiply-adds are written on pairs; a lane's 4 pixels are 2 pairs.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ inline f2 splat(float s) { return f2{s, s}; }
+__device__ inline f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ inline f2 exp2_2(f2 q) { return f2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)}; }
+__device__ inline f2 clamp_alpha2(f2 raw) { return f2{clamp_alpha(raw.x), clamp_alpha(raw.y)}; }
+
 __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                             const float *__restrict__ stream_rec,
                                                             float *__restrict__ img, float *__restrict__ final_T)
@@ -98,20 +107,24 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, w)) return;
     const float pxf = (float)w.x;
-    float pyf[4], T[4], cr[4], cg[4], cb[4];
+    f2 pyf[2], T[2], cr[2], cg[2], cb[2];   // pixel rows (y0, y0+1) and (y0+2, y0+3)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { pyf[j] = (float)(w.y0 + j); T[j] = 1.0f; cr[j] = cg[j] = cb[j] = 0.0f; }
+    for (int h = 0; h < 2; ++h) {
+        pyf[h] = f2{(float)(w.y0 + 2 * h), (float)(w.y0 + 2 * h + 1)};
+        T[h] = splat(1.0f);
+        cr[h] = cg[h] = cb[h] = splat(0.0f);
+    }
 
     auto blend = [&](const Rec &R) {
         if (rec_all_clamped_low(R)) {
             // alpha is 0.01 on the whole tile: no exponent, no exp
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float wgt = kAlphaMin * T[j];
-                cr[j] = fmaf(wgt, R_r(R), cr[j]);
-                cg[j] = fmaf(wgt, R_g(R), cg[j]);
-                cb[j] = fmaf(wgt, R_b(R), cb[j]);
-                T[j] = T[j] * (1.0f - kAlphaMin);
+            for (int h = 0; h < 2; ++h) {
+                const f2 wgt = splat(kAlphaMin) * T[h];
+                cr[h] = pk_fma(wgt, splat(R_r(R)), cr[h]);
+                cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
+                cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
+                T[h] = T[h] * splat(1.0f - kAlphaMin);
             }
             return;
         }
@@ -119,16 +132,15 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float dy = R_gy(R) - pyf[j];
-            const float q = fmaf(fmaf(R_D(R), dy, bdx), dy, adx2);
-            const float G = __builtin_amdgcn_exp2f(q);
-            const float a = clamp_alpha(R_o(R) * G);
-            const float wgt = a * T[j];
-            cr[j] = fmaf(wgt, R_r(R), cr[j]);
-            cg[j] = fmaf(wgt, R_g(R), cg[j]);
-            cb[j] = fmaf(wgt, R_b(R), cb[j]);
-            T[j] = T[j] * (1.0f - a);   // same rounding as the reference's cumprod of (1 - alpha)
+        for (int h = 0; h < 2; ++h) {
+            const f2 dy = splat(R_gy(R)) - pyf[h];
+            const f2 q = pk_fma(pk_fma(splat(R_D(R)), dy, splat(bdx)), dy, splat(adx2));
+            const f2 a = clamp_alpha2(splat(R_o(R)) * exp2_2(q));
+            const f2 wgt = a * T[h];
+            cr[h] = pk_fma(wgt, splat(R_r(R)), cr[h]);
+            cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
+            cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
+            T[h] = T[h] * (splat(1.0f) - a);   // same rounding as the reference's cumprod of (1 - alpha)
         }
     };
     if (w.begin < w.end) {
@@ -156,8 +168,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         const int y = w.y0 + j;
         if (y < w.ylim) {
             const size_t pix = (size_t)w.x * v.H + y;
-            img[pix * 3 + 0] = cr[j]; img[pix * 3 + 1] = cg[j]; img[pix * 3 + 2] = cb[j];
-            final_T[pix] = T[j];
+            img[pix * 3 + 0] = cr[j >> 1][j & 1]; img[pix * 3 + 1] = cg[j >> 1][j & 1]; img[pix * 3 + 2] = cb[j >> 1][j & 1];
+            final_T[pix] = T[j >> 1][j & 1];
         }
     }
 }
@@ -223,10 +235,10 @@ __device__ inline void store_pairgrad(float *dst, float v0, float v1, float v2, 
 // entries with index (k - begin) < nstop[j].
 template <bool CHECK, bool ATOMIC>
 __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ stream_rec, const float pxf,
-                                 const float (&pyf)[4], float (&T)[4], const float (&gr)[4], const float (&gg)[4],
-                                 const float (&gb)[4], const uint32_t (&nstop)[4], float *__restrict__ pairgrad)
+                                 const f2 (&pyf)[2], f2 (&T)[2], const f2 (&gr)[2], const f2 (&gg)[2],
+                                 const f2 (&gb)[2], const uint32_t (&nstop)[4], float *__restrict__ pairgrad)
 {
-    float suffix[4] = {0.f, 0.f, 0.f, 0.f};
+    f2 suffix[2] = {splat(0.f), splat(0.f)};
     const int lane = threadIdx.x & 63;
     auto entry = [&](const Rec &R, uint32_t k) {
         float *dst = pairgrad + (size_t)k * GSR_PAIRGRAD_FLOATS;
@@ -234,26 +246,30 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             // alpha = 0.01 on every pixel: only the transmittance recurrence, the colour sums and the
             // suffix remain; the clamp blocks every geometric gradient
             const float om = 1.0f - kAlphaMin, rcp = 1.0f / (1.0f - kAlphaMin);
-            float col[3] = {0.f, 0.f, 0.f};
+            f2 c_r = splat(0.f), c_g = splat(0.f), c_b = splat(0.f);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float t0 = T[j] * rcp;
-                float Tk = fmaf(fmaf(-om, t0, T[j]), rcp, t0);
-                float wgt = kAlphaMin * Tk;
-                const float cgd = fmaf(R_b(R), gb[j], fmaf(R_g(R), gg[j], R_r(R) * gr[j]));
-                float suf = fmaf(wgt, cgd, suffix[j]);
+            for (int h = 0; h < 2; ++h) {
+                const f2 t0 = T[h] * splat(rcp);
+                f2 Tk = pk_fma(pk_fma(splat(-om), t0, T[h]), splat(rcp), t0);
+                f2 wgt = splat(kAlphaMin) * Tk;
+                const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(R_r(R)) * gr[h]));
+                f2 suf = pk_fma(wgt, cgd, suffix[h]);
                 if (CHECK) {
-                    const bool on = (k - w.begin) < nstop[j];
-                    Tk = on ? Tk : T[j];
-                    suf = on ? suf : suffix[j];
-                    wgt = on ? wgt : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const bool on = (k - w.begin) < nstop[2 * h + e];
+                        Tk[e] = on ? Tk[e] : T[h][e];
+                        suf[e] = on ? suf[e] : suffix[h][e];
+                        wgt[e] = on ? wgt[e] : 0.0f;
+                    }
                 }
-                T[j] = Tk;
-                suffix[j] = suf;
-                col[0] = fmaf(wgt, gr[j], col[0]);
-                col[1] = fmaf(wgt, gg[j], col[1]);
-                col[2] = fmaf(wgt, gb[j], col[2]);
+                T[h] = Tk;
+                suffix[h] = suf;
+                c_r = pk_fma(wgt, gr[h], c_r);
+                c_g = pk_fma(wgt, gg[h], c_g);
+                c_b = pk_fma(wgt, gb[h], c_b);
             }
+            float col[3] = {c_r.x + c_r.y, c_g.x + c_g.y, c_b.x + c_b.y};
             wave_sum_to_lane63(col);
             if (lane == 63) store_pairgrad<ATOMIC>(dst, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, col[0], col[1], col[2]);
             return;
@@ -263,63 +279,69 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         const float bdx = R_B(R) * dx;
         const float cadx = R_ca(R) * dx;   // with v = conic * d:  v_x = a dx + bh dy,  v_y = bh dx + d dy
         const float cbdx = R_cbh(R) * dx;
-        float s_vx = 0.f, s_vy = 0.f, s_xx = 0.f, s_xy = 0.f, s_yy = 0.f, s_o = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f;
+        const f2 z = splat(0.f);
+        f2 s_vx = z, s_vy = z, s_xx = z, s_xy = z, s_yy = z, s_o = z, s_r = z, s_g = z, s_b = z;
         bool any_pass = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float dy = R_gy(R) - pyf[j];
-            const float q = fmaf(fmaf(R_D(R), dy, bdx), dy, adx2);
-            const float G = __builtin_amdgcn_exp2f(q);
-            const float raw = R_o(R) * G;
-            const float a = clamp_alpha(raw);
+        for (int h = 0; h < 2; ++h) {
+            const f2 dy = splat(R_gy(R)) - pyf[h];
+            const f2 q = pk_fma(pk_fma(splat(R_D(R)), dy, splat(bdx)), dy, splat(adx2));
+            const f2 G = exp2_2(q);
+            const f2 raw = splat(R_o(R)) * G;
+            const f2 a = clamp_alpha2(raw);
             // T_k = T_{k+1} / (1 - a), correctly rounded: quotient estimate, exact remainder (fma), one
             // correction.  A plain T * rcp(1 - a) is not good enough here: most entries of a long list
             // have the same a (0.01), so the reciprocal's rounding error repeats with the same sign
             // at every step and the transmittance drifts by ~1e-4 over a few thousand entries.
-            const float om = 1.0f - a;
-            const float rcp = __builtin_amdgcn_rcpf(om);
-            const float t0 = T[j] * rcp;
-            float Tk = fmaf(fmaf(-om, t0, T[j]), rcp, t0);   // transmittance in front of this entry
-            float wgt = a * Tk;
-            const float cgd = fmaf(R_b(R), gb[j], fmaf(R_g(R), gg[j], R_r(R) * gr[j]));
-            float d_a = fmaf(Tk, cgd, -(suffix[j] * rcp));
-            float suf = fmaf(wgt, cgd, suffix[j]);
+            const f2 om = splat(1.0f) - a;
+            const f2 rcp = f2{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+            const f2 t0 = T[h] * rcp;
+            f2 Tk = pk_fma(pk_fma(-om, t0, T[h]), rcp, t0);   // transmittance in front of this entry
+            f2 wgt = a * Tk;
+            const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(R_r(R)) * gr[h]));
+            f2 d_a = pk_fma(Tk, cgd, -(suffix[h] * rcp));
+            f2 suf = pk_fma(wgt, cgd, suffix[h]);
             if (CHECK) {
-                const bool on = (k - w.begin) < nstop[j];
-                Tk = on ? Tk : T[j];
-                suf = on ? suf : suffix[j];
-                wgt = on ? wgt : 0.0f;
-                d_a = on ? d_a : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool on = (k - w.begin) < nstop[2 * h + e];
+                    Tk[e] = on ? Tk[e] : T[h][e];
+                    suf[e] = on ? suf[e] : suffix[h][e];
+                    wgt[e] = on ? wgt[e] : 0.0f;
+                    d_a[e] = on ? d_a[e] : 0.0f;
+                }
             }
-            T[j] = Tk;
-            suffix[j] = suf;
-            s_r = fmaf(wgt, gr[j], s_r);
-            s_g = fmaf(wgt, gg[j], s_g);
-            s_b = fmaf(wgt, gb[j], s_b);
-            const bool pass = (a == raw);                  // clamp passes gradient on [0.01, 0.99]
-            any_pass |= pass;
-            const float d_raw = pass ? d_a : 0.0f;
-            s_o = fmaf(d_raw, G, s_o);
-            const float h = d_raw * a;                     // = -2 dL/d(exponent); a == raw when it matters
+            T[h] = Tk;
+            suffix[h] = suf;
+            s_r = pk_fma(wgt, gr[h], s_r);
+            s_g = pk_fma(wgt, gg[h], s_g);
+            s_b = pk_fma(wgt, gb[h], s_b);
+            // clamp passes gradient on [0.01, 0.99]: exactly when the clamped value equals the input
+            const bool p0 = (a.x == raw.x), p1 = (a.y == raw.y);
+            any_pass |= p0 | p1;
+            const f2 d_raw = f2{p0 ? d_a.x : 0.0f, p1 ? d_a.y : 0.0f};
+            s_o = pk_fma(d_raw, G, s_o);
+            const f2 hh = d_raw * a;                       // = -2 dL/d(exponent); a == raw when it matters
             // Sums are taken in the conic-weighted coordinates v: summing h*d and weighting by the
             // conic afterwards would cancel large coherent sums for elongated Gaussians.
-            const float vx = fmaf(R_cbh(R), dy, cadx);
-            const float vy = fmaf(R_cd(R), dy, cbdx);
-            const float hvx = h * vx, hvy = h * vy;
+            const f2 vx = pk_fma(splat(R_cbh(R)), dy, splat(cadx));
+            const f2 vy = pk_fma(splat(R_cd(R)), dy, splat(cbdx));
+            const f2 hvx = hh * vx, hvy = hh * vy;
             s_vx += hvx;
             s_vy += hvy;
-            s_xx = fmaf(hvx, vx, s_xx);
-            s_xy = fmaf(hvx, vy, s_xy);
-            s_yy = fmaf(hvy, vy, s_yy);
+            s_xx = pk_fma(hvx, vx, s_xx);
+            s_xy = pk_fma(hvx, vy, s_xy);
+            s_yy = pk_fma(hvy, vy, s_yy);
         }
         const bool any_geom = __ballot(any_pass) != 0ull;
         if (any_geom) {
-            float val[9] = {s_vx, s_vy, s_xx, s_xy, s_yy, s_o, s_r, s_g, s_b};
+            float val[9] = {s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y, s_yy.x + s_yy.y,
+                            s_o.x + s_o.y,   s_r.x + s_r.y,   s_g.x + s_g.y,   s_b.x + s_b.y};
             wave_sum_to_lane63(val);
             if (lane == 63)
                 store_pairgrad<ATOMIC>(dst, val[0], val[1], val[2], val[3], val[4], val[5], val[6], val[7], val[8]);
         } else {
-            float col[3] = {s_r, s_g, s_b};
+            float col[3] = {s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y};
             wave_sum_to_lane63(col);
             if (lane == 63) store_pairgrad<ATOMIC>(dst, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, col[0], col[1], col[2]);
         }
@@ -357,18 +379,19 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
     if (!wave_setup(v, tile_offsets, w)) return;
     if (w.begin == w.end) return;
     const float pxf = (float)w.x;
-    float pyf[4], T[4], gr[4], gg[4], gb[4];
+    f2 pyf[2], T[2], gr[2], gg[2], gb[2];
     bool tiny = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int y = w.y0 + j;
-        pyf[j] = (float)y;
-        T[j] = 0.0f; gr[j] = gg[j] = gb[j] = 0.0f;   // a pixel outside the tile contributes exact zeros
+        const int h = j >> 1, e = j & 1;
+        pyf[h][e] = (float)y;
+        T[h][e] = 0.0f; gr[h][e] = gg[h][e] = gb[h][e] = 0.0f;   // a pixel outside the tile contributes exact zeros
         if (w.vx && y < w.ylim) {
             const size_t pix = (size_t)w.x * v.H + y;
-            T[j] = final_T[pix];
-            gr[j] = dimg[pix * 3 + 0]; gg[j] = dimg[pix * 3 + 1]; gb[j] = dimg[pix * 3 + 2];
-            tiny |= !(T[j] >= kTinyT);
+            T[h][e] = final_T[pix];
+            gr[h][e] = dimg[pix * 3 + 0]; gg[h][e] = dimg[pix * 3 + 1]; gb[h][e] = dimg[pix * 3 + 2];
+            tiny |= !(T[h][e] >= kTinyT);
         }
     }
     uint32_t nstop[4] = {0u, 0u, 0u, 0u};
@@ -391,7 +414,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
             const float bdx = R_B(R) * dx;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float dy = R_gy(R) - pyf[j];
+                const float dy = R_gy(R) - pyf[j >> 1][j & 1];
                 const float q = fmaf(fmaf(R_D(R), dy, bdx), dy, adx2);
                 const float a = low ? kAlphaMin : clamp_alpha(R_o(R) * __builtin_amdgcn_exp2f(q));
                 Tf[j] = Tf[j] * (1.0f - a);
@@ -403,7 +426,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool inside = w.vx && (w.y0 + j) < w.ylim;
-            if (nstop[j] != len) T[j] = inside ? Ts[j] : 0.0f;
+            if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
         bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad);
     } else {

@@ -1,0 +1,98 @@
+// Micro-benchmark: issue rate of a few VALU instruction kinds on gfx950 with every SIMD full
+// (8 waves/SIMD).  Prints cycles per wave-instruction per SIMD.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int ITERS = 4096, UNROLL = 16;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float *out, float seed)
+{
+    float a[UNROLL];
+    f2 p[UNROLL];
+    for (int i = 0; i < UNROLL; ++i) { a[i] = seed + i + threadIdx.x; p[i] = f2{a[i], a[i] + 1.f}; }
+    const float m = seed * 0.999f, c = seed * 0.001f;
+    const f2 pm = {m, m}, pc = {c, c};
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pm), "v"(pc));
+            if (KIND == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == 3) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+            if (KIND == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == 5) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(m), "v"(c));
+            if (KIND == 6) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (KIND == 7) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 8) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
+            if (KIND == 9) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m));
+            if (KIND == 10) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (KIND == 11) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 12) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a[i]), "v"(m) : "vcc");
+            if (KIND == 13) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "s"(m), "v"(c));
+            if (KIND == 14) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 15) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(a[i]) : "v"(m));
+            if (KIND == 16) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
+            if (KIND == 17) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (KIND == 18) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(m) : "s10", "s11");
+        }
+    }
+    unsigned long long t0 = 0, t1 = 0, r0 = 0, r1 = 0;
+    (void)t0; (void)t1; (void)r0; (void)r1;
+    float s = 0;
+    for (int i = 0; i < UNROLL; ++i) s += a[i] + p[i][0] + p[i][1];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int KIND>
+void run(const char *name, float *out)
+{
+    const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU = 8 waves per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double insts_per_simd = (double)ITERS * UNROLL * 8;   // 8 waves per SIMD
+    const double cyc = ms * 1e-3 * 2.4e9 / insts_per_simd;
+    printf("%-22s %8.3f ms  %6.2f cycles/wave-instr/SIMD (at 2.4 GHz)\n", name, ms, cyc);
+}
+
+__global__ void clk(unsigned long long *o)
+{
+    float a = threadIdx.x;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 200000; ++i) asm volatile("v_fmac_f32_e32 %0, %0, %0" : "+v"(a));
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { o[0] = c1 - c0; o[1] = r1 - r0; }
+    if (a == 123.f) o[2] = 1;
+}
+void clock_probe()
+{
+    unsigned long long *d, h[2];
+    hipMalloc(&d, 64);
+    hipLaunchKernelGGL(clk, dim3(2048), dim3(256), 0, 0, d);
+    hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    printf("shader clock under full VALU load: %.0f MHz (memtime %llu ticks / memrealtime %llu ticks of 10 ns)\n",
+           (double)h[0] / (double)h[1] * 100.0, h[0], h[1]);
+}
+
+int main()
+{
+    float *out; hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+    run<0>("v_fma_f32", out); run<5>("v_fma_f32 (sgpr op)", out); run<7>("v_mul_f32", out);
+    run<1>("v_pk_fma_f32", out); run<8>("v_pk_mul_f32", out);
+    run<2>("v_exp_f32", out); run<4>("v_rcp_f32", out); run<3>("v_add_f32_dpp", out);
+    run<6>("v_med3_f32", out); run<9>("v_cndmask_b32_e32 vcc", out); run<18>("v_cndmask_b32_e64 sgpr", out);
+    run<10>("v_fmac_f32_e32", out); run<13>("v_fmac_f32_e32 (sgpr)", out); run<17>("v_fma_f32 acc form", out);
+    run<11>("v_add_f32_e32", out); run<14>("v_max_f32_e32", out); run<12>("v_cmp_lt_f32_e32", out);
+    run<15>("v_mov_b32_e32", out); run<16>("v_pk_add_f32", out);
+    clock_probe();
+    return 0;
+}
