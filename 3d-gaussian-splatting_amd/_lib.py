@@ -17,8 +17,8 @@ PAIRGRAD_FLOATS = 12
 
 # Every symbol include/gsr.h declares.
 SYMBOLS = (
-    "gsr_last_error", "gsr_version", "gsr_preprocess_fwd", "gsr_preprocess_bwd",
-    "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
+    "gsr_last_error", "gsr_version", "gsr_preprocess_fwd", "gsr_preprocess_bwd", "gsr_preprocess_bwd_workspace_bytes",
+    "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_sort_pairs64", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
     "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_lists_workspace_bytes", "gsr_bin_lists",
     "gsr_composite_fwd", "gsr_composite_bwd",
 )
@@ -65,18 +65,19 @@ def load():
             raise RuntimeError(f"{LIB_PATH} does not export {name}")
     lib.gsr_last_error.restype = C.c_char_p
     for name in ("gsr_sort_workspace_bytes", "gsr_scan_workspace_bytes", "gsr_bin_offsets_workspace_bytes",
-                 "gsr_bin_lists_workspace_bytes"):
+                 "gsr_bin_lists_workspace_bytes", "gsr_preprocess_bwd_workspace_bytes"):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.c_uint32]
     vp = C.c_void_p
     lib.gsr_preprocess_fwd.argtypes = [C.POINTER(GsrView)] + [vp] * 16
-    lib.gsr_preprocess_bwd.argtypes = [C.POINTER(GsrView)] + [vp] * 16 + [C.c_int, vp]
+    lib.gsr_preprocess_bwd.argtypes = [C.POINTER(GsrView)] + [vp] * 15 + [C.c_int, vp, C.c_size_t, vp]
     lib.gsr_sort_pairs.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
+    lib.gsr_sort_pairs64.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
     lib.gsr_exclusive_scan.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_size_t, vp]
     lib.gsr_bin_offsets.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_bin_lists.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_composite_fwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp]
-    lib.gsr_composite_bwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, C.c_uint32, vp, vp]
+    lib.gsr_composite_bwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, C.c_uint32, vp, vp]
     _lib = lib
     return lib
 

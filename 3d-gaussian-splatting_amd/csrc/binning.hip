@@ -36,8 +36,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
                                                          const int32_t *__restrict__ bbox,
                                                          const uint32_t *__restrict__ ntiles,
                                                          uint32_t *__restrict__ tile_key,
-                                                         uint32_t *__restrict__ slot_id,
-                                                         uint32_t *__restrict__ owner, uint32_t num_pairs)
+                                                         uint64_t *__restrict__ owner_slot, uint32_t num_pairs)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= v.n) return;
@@ -52,8 +51,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
         for (int yi = y0; yi <= y1; ++yi) {
             if (e < num_pairs) {  // guards a stale num_pairs; never taken on consistent input
                 tile_key[e] = (uint32_t)(yi + v.nbh * xi);
-                slot_id[e] = e;
-                owner[e] = (uint32_t)g;
+                owner_slot[e] = ((uint64_t)(uint32_t)g << 32) | (uint64_t)e;   // carried through the tile sort
             }
             ++e;
         }
@@ -92,20 +90,19 @@ __device__ inline bool tile_all_clamped_low(float gx, float gy, float A, float B
     return __log2f(o) - fmin + 4.0e-6f * mag + 1.0e-4f < -6.6438561898f;
 }
 
-// One thread per sorted position p: copy the owner's splat record into the stream, record where
-// slot e went, mark tile boundaries, and flag (sign bit of the opacity) records whose alpha is
-// 0.01 on the whole tile so the compositing kernels can skip their exponentials.
+// One thread per sorted position p: copy the owner's splat record into the stream, note the
+// owner and its emission slot, mark tile boundaries, and flag (sign bit of the opacity) records
+// whose alpha is 0.01 on the whole tile so the compositing kernels can skip their exponentials.
 __global__ __launch_bounds__(256) void finalize_lists_kernel(
-    ViewK v, const uint32_t *__restrict__ sorted_tile, const uint32_t *__restrict__ sorted_slot,
-    const uint32_t *__restrict__ owner, const float *__restrict__ rec, uint32_t num_pairs, uint32_t T,
-    uint32_t *__restrict__ tile_offsets, uint32_t *__restrict__ pair_pos, uint32_t *__restrict__ sorted_gauss,
-    float *__restrict__ stream_rec)
+    ViewK v, const uint32_t *__restrict__ sorted_tile, const uint64_t *__restrict__ sorted_owner_slot,
+    const float *__restrict__ rec, uint32_t num_pairs, uint32_t T, uint32_t *__restrict__ tile_offsets,
+    uint32_t *__restrict__ pair_slot, uint32_t *__restrict__ sorted_gauss, float *__restrict__ stream_rec)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= num_pairs) return;
-    const uint32_t e = sorted_slot[p];
-    const uint32_t g = owner[e];
-    pair_pos[e] = p;
+    const uint64_t os = sorted_owner_slot[p];
+    const uint32_t g = (uint32_t)(os >> 32);
+    pair_slot[p] = (uint32_t)os;
     sorted_gauss[p] = g;
     const float4 *src = reinterpret_cast<const float4 *>(rec + (size_t)g * GSR_REC_FLOATS);
     float4 *dst = reinterpret_cast<float4 *>(stream_rec + (size_t)p * GSR_REC_FLOATS);
@@ -177,12 +174,12 @@ extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint
 extern "C" size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs)
 {
     const size_t arr = align256((size_t)(num_pairs ? num_pairs : 1) * sizeof(uint32_t));
-    return 5 * arr + gsr_sort_workspace_bytes(num_pairs);
+    return 6 * arr + gsr_sort_workspace_bytes(num_pairs);   // 2 key arrays + 2 arrays of 64-bit payloads
 }
 
 extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_base, const int32_t *bbox,
                              const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
-                             uint32_t *tile_offsets, uint32_t *pair_pos, uint32_t *sorted_gauss,
+                             uint32_t *tile_offsets, uint32_t *pair_slot, uint32_t *sorted_gauss,
                              float *stream_rec, void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -197,26 +194,25 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_bas
         gsr_set_error("gsr_bin_lists: workspace too small");
         return GSR_ERR_ARG;
     }
-    if (!slot_base || !bbox || !ntiles || !rec || !pair_pos || !sorted_gauss || !stream_rec) {
+    if (!slot_base || !bbox || !ntiles || !rec || !pair_slot || !sorted_gauss || !stream_rec) {
         gsr_set_error("gsr_bin_lists: null pointer");
         return GSR_ERR_ARG;
     }
     const size_t arr = align256((size_t)num_pairs * sizeof(uint32_t));
     char *ws = (char *)workspace;
     uint32_t *tile_key = (uint32_t *)ws;
-    uint32_t *slot_id = (uint32_t *)(ws + arr);
-    uint32_t *owner = (uint32_t *)(ws + 2 * arr);
-    uint32_t *sorted_tile = (uint32_t *)(ws + 3 * arr);
-    uint32_t *sorted_slot = (uint32_t *)(ws + 4 * arr);
-    void *sort_ws = ws + 5 * arr;
-    const size_t sort_bytes = workspace_bytes - 5 * arr;
+    uint32_t *sorted_tile = (uint32_t *)(ws + arr);
+    uint64_t *owner_slot = (uint64_t *)(ws + 2 * arr);
+    uint64_t *sorted_owner_slot = (uint64_t *)(ws + 4 * arr);
+    void *sort_ws = ws + 6 * arr;
+    const size_t sort_bytes = workspace_bytes - 6 * arr;
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, slot_base, bbox, ntiles,
-                       tile_key, slot_id, owner, num_pairs);
-    if (int e = gsr_sort_pairs(tile_key, slot_id, sorted_tile, sorted_slot, num_pairs, 0, bits_for((uint32_t)v.T),
-                               sort_ws, sort_bytes, stream))
+                       tile_key, owner_slot, num_pairs);
+    if (int e = gsr_sort_pairs64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0,
+                                 bits_for((uint32_t)v.T), sort_ws, sort_bytes, stream))
         return e;
     hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v, sorted_tile,
-                       sorted_slot, owner, rec, num_pairs, (uint32_t)v.T, tile_offsets, pair_pos, sorted_gauss,
+                       sorted_owner_slot, rec, num_pairs, (uint32_t)v.T, tile_offsets, pair_slot, sorted_gauss,
                        stream_rec);
     return gsr_check_launch("bin_lists");
 }

@@ -85,6 +85,22 @@ __device__ inline void rec_request(const float *__restrict__ stream_rec, uint32_
 }
 __device__ inline void rec_wait(Rec &R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b)::"memory"); }
 
+// The same plus the record's emission slot (where its gradient record goes), for the backward.
+__device__ inline void rec_request(const float *__restrict__ stream_rec, const uint32_t *__restrict__ pair_slot,
+                                   uint32_t k, Rec &R, uint32_t &slot)
+{
+    const float *p = stream_rec + (size_t)k * GSR_REC_FLOATS;
+    const uint32_t *q = pair_slot + k;
+    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dword %2, %4, 0x0"
+                 : "=&s"(R.a), "=&s"(R.b), "=&s"(slot)
+                 : "s"(p), "s"(q)
+                 : "memory");
+}
+__device__ inline void rec_wait(Rec &R, uint32_t &slot)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(slot)::"memory");
+}
+
 // The list builder sets the sign bit of the opacity when alpha is pinned at 0.01 on every pixel of
 // the tile (wave-uniform: a scalar compare and branch).
 __device__ inline bool rec_all_clamped_low(const Rec &R) { return __float_as_int(R_o(R)) < 0; }
@@ -236,12 +252,13 @@ __device__ inline void store_pairgrad(float *dst, float v0, float v1, float v2, 
 template <bool CHECK, bool ATOMIC>
 __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ stream_rec, const float pxf,
                                  const f2 (&pyf)[2], f2 (&T)[2], const f2 (&gr)[2], const f2 (&gg)[2],
-                                 const f2 (&gb)[2], const uint32_t (&nstop)[4], float *__restrict__ pairgrad)
+                                 const f2 (&gb)[2], const uint32_t (&nstop)[4],
+                                 const uint32_t *__restrict__ pair_slot, float *__restrict__ pairgrad)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
     const int lane = threadIdx.x & 63;
-    auto entry = [&](const Rec &R, uint32_t k) {
-        float *dst = pairgrad + (size_t)k * GSR_PAIRGRAD_FLOATS;
+    auto entry = [&](const Rec &R, uint32_t k, uint32_t slot) {
+        float *dst = pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS;   // a Gaussian's records are contiguous
         if (rec_all_clamped_low(R)) {
             // alpha = 0.01 on every pixel: only the transmittance recurrence, the colour sums and the
             // suffix remain; the clamp blocks every geometric gradient
@@ -349,21 +366,22 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     // back to front, two record buffers alternating (see composite_fwd_kernel)
     uint32_t k = w.end - 1;   // the caller guarantees a non-empty list
     Rec A, B;
-    rec_request(stream_rec, k, A);
+    uint32_t sa, sb;
+    rec_request(stream_rec, pair_slot, k, A, sa);
     for (;;) {
-        rec_wait(A);
-        rec_request(stream_rec, k > w.begin ? k - 1 : k, B);
-        entry(A, k);
+        rec_wait(A, sa);
+        rec_request(stream_rec, pair_slot, k > w.begin ? k - 1 : k, B, sb);
+        entry(A, k, sa);
         if (k == w.begin) break;
         --k;
-        rec_wait(B);
-        rec_request(stream_rec, k > w.begin ? k - 1 : k, A);
-        entry(B, k);
+        rec_wait(B, sb);
+        rec_request(stream_rec, pair_slot, k > w.begin ? k - 1 : k, A, sa);
+        entry(B, k, sb);
         if (k == w.begin) break;
         --k;
     }
-    rec_wait(A);
-    rec_wait(B);
+    rec_wait(A, sa);
+    rec_wait(B, sb);
 }
 
 // ATOMIC = several waves share a tile (L > 16): their sums meet in pairgrad through float atomics
@@ -373,6 +391,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
                                                             const float *__restrict__ stream_rec,
                                                             const float *__restrict__ final_T,
                                                             const float *__restrict__ dimg,
+                                                            const uint32_t *__restrict__ pair_slot,
                                                             float *__restrict__ pairgrad)
 {
     WaveGeom w;
@@ -428,9 +447,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
             const bool inside = w.vx && (w.y0 + j) < w.ylim;
             if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
-        bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad);
+        bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pair_slot, pairgrad);
     } else {
-        bwd_sweep<false, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad);
+        bwd_sweep<false, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pair_slot, pairgrad);
     }
 }
 
@@ -450,13 +469,13 @@ extern "C" int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile
 }
 
 extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, const float *stream_rec,
-                                 const float *final_T, const float *dimg, uint32_t num_pairs, float *pairgrad,
-                                 void *stream)
+                                 const uint32_t *pair_slot, const float *final_T, const float *dimg,
+                                 uint32_t num_pairs, float *pairgrad, void *stream)
 {
     ViewK v;
     if (int e = gsr_make_view(view_host, &v)) return e;
     if (num_pairs == 0) return GSR_OK;
-    if (!tile_offsets || !stream_rec || !final_T || !dimg || !pairgrad) {
+    if (!tile_offsets || !stream_rec || !pair_slot || !final_T || !dimg || !pairgrad) {
         gsr_set_error("gsr_composite_bwd: null pointer");
         return GSR_ERR_ARG;
     }
@@ -466,10 +485,10 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
     if (S > 1) {
         (void)hipMemsetAsync(pairgrad, 0, (size_t)num_pairs * GSR_PAIRGRAD_FLOATS * sizeof(float), (hipStream_t)stream);
         hipLaunchKernelGGL(composite_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pairgrad);
+                           stream_rec, final_T, dimg, pair_slot, pairgrad);
     } else {
         hipLaunchKernelGGL(composite_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pairgrad);
+                           stream_rec, final_T, dimg, pair_slot, pairgrad);
     }
     return gsr_check_launch("composite_bwd");
 }

@@ -306,86 +306,153 @@ __device__ inline void put(float *dst, float v)
     if (ACC) *dst += v; else *dst = v;
 }
 
+// Sum of each Gaussian's per-tile gradient records -> gsum[N,12] (9 used).  The records of
+// Gaussian g are the contiguous slots slot_base[g] .. slot_base[g]+ntiles[g] of pairgrad.  One
+// thread per Gaussian walks its slots in order; a Gaussian with many tiles is summed by the whole
+// wave (strided partial sums, then a fixed butterfly), so one huge splat cannot serialise thousands
+// of dependent loads in a single lane.  Both orders are fixed: the result is reproducible.
+constexpr uint32_t kHeavyTiles = 96;
+
+__device__ inline void add_record(double (&acc)[9], const float *__restrict__ pairgrad, uint32_t slot)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS);
+    const float4 a = src[0], b = src[1];
+    const float c8 = pairgrad[(size_t)slot * GSR_PAIRGRAD_FLOATS + 8];
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c8;
+}
+
+__global__ __launch_bounds__(256) void pair_reduce_kernel(int n, const uint8_t *__restrict__ mask,
+                                                          const uint32_t *__restrict__ slot_base,
+                                                          const uint32_t *__restrict__ ntiles,
+                                                          const float *__restrict__ pairgrad,
+                                                          float *__restrict__ gsum)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < n && mask[i];
+    const uint32_t nt = live ? ntiles[i] : 0u;
+    const uint32_t e0 = live ? slot_base[i] : 0u;
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    const bool heavy = nt >= kHeavyTiles;
+    if (!heavy)
+        for (uint32_t j = 0; j < nt; ++j) add_record(acc, pairgrad, e0 + j);
+    unsigned long long todo = __ballot(heavy);
+    while (todo) {
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t E0 = __shfl(e0, src_lane, 64), NT = __shfl(nt, src_lane, 64);
+        double part[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) part[k] = 0.0;
+        for (uint32_t j = lane; j < NT; j += 64) add_record(part, pairgrad, E0 + j);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part[k] += __shfl_xor(part[k], d, 64);
+            if (lane == src_lane) acc[k] = part[k];
+        }
+    }
+    if (i < n) {
+        float4 *dst = reinterpret_cast<float4 *>(gsum + (size_t)i * 12);
+        dst[0] = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+        dst[1] = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
+        dst[2] = make_float4((float)acc[8], 0.f, 0.f, 0.f);
+    }
+}
+
 template <bool ACC>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     ViewK v, const float *__restrict__ coords, const float *__restrict__ scale_raw,
     const float *__restrict__ rot_raw, const float *__restrict__ opac_raw, const float *__restrict__ sh,
-    const uint8_t *__restrict__ mask, const uint32_t *__restrict__ slot_base,
-    const uint32_t *__restrict__ ntiles, const uint32_t *__restrict__ pair_pos,
-    const float *__restrict__ pairgrad, float *__restrict__ g_coords, float *__restrict__ g_scale,
-    float *__restrict__ g_rot, float *__restrict__ g_opac, float *__restrict__ g_sh,
+    const uint8_t *__restrict__ mask, const float *__restrict__ gsum, float *__restrict__ g_coords,
+    float *__restrict__ g_scale, float *__restrict__ g_rot, float *__restrict__ g_opac, float *__restrict__ g_sh,
     float *__restrict__ g_screen)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.n) return;
     float gc[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, gr[4] = {0.f, 0.f, 0.f, 0.f};
     float gsc[2] = {0.f, 0.f}, go = 0.f;
-    float gsh[3][16];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) gsh[c][k] = 0.f;
+    float4 *dsh = reinterpret_cast<float4 *>(g_sh + (size_t)i * 48);
 
-    if (mask[i]) {
-        // sum of this Gaussian's per-tile records, in slot order (fixed => reproducible)
-        double acc[9];
+    if (!mask[i]) {
+        if (!ACC) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-        const uint32_t nt = ntiles[i], e0 = slot_base[i];
-        for (uint32_t j = 0; j < nt; ++j) {
-            const uint32_t pp = pair_pos[e0 + j];
-            const float4 *src = reinterpret_cast<const float4 *>(pairgrad + (size_t)pp * GSR_PAIRGRAD_FLOATS);
-            const float4 a = src[0], b = src[1];
-            const float c8 = pairgrad[(size_t)pp * GSR_PAIRGRAD_FLOATS + 8];
-            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c8;
+            for (int k = 0; k < 12; ++k) dsh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    } else {
         // With h = -2 dL/d(exponent) per pixel, d = centre - pixel, C = inv(cov2) (symmetric part) and
-        // v = C d, the records hold: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2,
+        // v = C d, the summed records hold: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2,
         // dL/d(opacity), dL/d(colour).  exponent = d^T C d, so
         //   dL/d(centre) = sum (-h/2) (2 v) = -sum h v,     dL/d(cov2) = sum (-h/2) (-v v^T) = 1/2 sum h v v^T.
-        const double d_px = -acc[0], d_py = -acc[1];
-        const double D[2][2] = {{0.5 * acc[2], 0.5 * acc[3]}, {0.5 * acc[3], 0.5 * acc[4]}};
-        const double d_o = acc[5];
-        const double d_col[3] = {acc[6], acc[7], acc[8]};
+        const float4 *gsrc = reinterpret_cast<const float4 *>(gsum + (size_t)i * 12);
+        const float4 s0 = gsrc[0], s1 = gsrc[1], s2 = gsrc[2];
+        const double d_px = -(double)s0.x, d_py = -(double)s0.y;
+        const double D[2][2] = {{0.5 * (double)s0.z, 0.5 * (double)s0.w}, {0.5 * (double)s0.w, 0.5 * (double)s1.x}};
+        const double d_o = s1.y;
+        const float d_col[3] = {s1.z, s1.w, s2.x};
 
         const float p[3] = {coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
         const float sr[3] = {scale_raw[3 * i], scale_raw[3 * i + 1], scale_raw[3 * i + 2]};
         const float4 q4 = reinterpret_cast<const float4 *>(rot_raw)[i];
         const float qr[4] = {q4.x, q4.y, q4.z, q4.w};
-        Geom g;
-        geometry(v, p, sr, qr, g);
         double gp[3] = {0.0, 0.0, 0.0};
         // opacity = sigmoid(raw)
         const float o = 1.0f / (1.0f + expf(-opac_raw[i]));
         go = (float)(d_o * (double)(o * (1.0f - o)));
 
-        // colour = max(sh . basis + 0.5, 0): gradient where the sum is >= 0 (torch.clamp rule)
+        // colour = max(sh . basis + 0.5, 0): gradient where the sum is >= 0 (torch.clamp rule).
+        // One channel at a time keeps the register footprint small.
         {
-            float co[3][16], bs[16];
-            load_sh(sh, i, v.K, co);
+            float bs[16];
             const float dx = p[0] - v.cam[0], dy = p[1] - v.cam[1], dz = p[2] - v.cam[2];
             sh_basis(v.deg, dx, dy, dz, bs);
+            const float4 *src = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
+                float co[16];
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (v4 * 4 < v.K) t = src[ch * 4 + v4];
+                    co[v4 * 4 + 0] = t.x; co[v4 * 4 + 1] = t.y; co[v4 * 4 + 2] = t.z; co[v4 * 4 + 3] = t.w;
+                }
                 float a = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    if (k < v.K) a += bs[k] * co[ch][k];
+                    if (k < v.K) a += bs[k] * co[k];
                 a += 0.5f;
+                const float dc = (a >= 0.0f) ? d_col[ch] : 0.0f;
                 if (a >= 0.0f) {
-                    const float dc = (float)d_col[ch];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        if (k < v.K) gsh[ch][k] = dc * bs[k];
                     float dd[3];
-                    sh_dir_grad(v.deg, dx, dy, dz, co[ch], dd);
-                    gp[0] += d_col[ch] * (double)dd[0];
-                    gp[1] += d_col[ch] * (double)dd[1];
-                    gp[2] += d_col[ch] * (double)dd[2];
+                    sh_dir_grad(v.deg, dx, dy, dz, co, dd);
+                    gp[0] += (double)dc * (double)dd[0];
+                    gp[1] += (double)dc * (double)dd[1];
+                    gp[2] += (double)dc * (double)dd[2];
+                }
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    float4 o4;
+                    o4.x = (4 * v4 + 0 < v.K) ? dc * bs[4 * v4 + 0] : 0.0f;
+                    o4.y = (4 * v4 + 1 < v.K) ? dc * bs[4 * v4 + 1] : 0.0f;
+                    o4.z = (4 * v4 + 2 < v.K) ? dc * bs[4 * v4 + 2] : 0.0f;
+                    o4.w = (4 * v4 + 3 < v.K) ? dc * bs[4 * v4 + 3] : 0.0f;
+                    if (ACC) {
+                        if (4 * v4 < v.K) {
+                            const float4 t = dsh[ch * 4 + v4];
+                            o4.x += t.x; o4.y += t.y; o4.z += t.z; o4.w += t.w;
+                            dsh[ch * 4 + v4] = o4;
+                        }
+                    } else {
+                        dsh[ch * 4 + v4] = o4;
+                    }
                 }
             }
         }
+        Geom g;
+        geometry(v, p, sr, qr, g);
         // pixel centre -> NDC (+ screen_coords) -> clip -> world  (Utils/Camera.py:102-115)
         {
             const double dn[3] = {d_px * 0.5 * (double)v.Wf, d_py * -0.5 * (double)v.Hf, 0.0};
@@ -507,15 +574,6 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     // screen_coords is a fresh leaf of every render (GaussianRenderer.py:64): its gradient belongs to
     // this view alone and is never accumulated
     g_screen[3 * i] = gsc[0]; g_screen[3 * i + 1] = gsc[1]; g_screen[3 * i + 2] = 0.0f;
-    float4 *dsh = reinterpret_cast<float4 *>(g_sh + (size_t)i * 48);
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int v4 = 0; v4 < 4; ++v4) {
-            float4 o4 = make_float4(gsh[c][4 * v4], gsh[c][4 * v4 + 1], gsh[c][4 * v4 + 2], gsh[c][4 * v4 + 3]);
-            if (ACC) { const float4 t = dsh[c * 4 + v4]; o4.x += t.x; o4.y += t.y; o4.z += t.z; o4.w += t.w; }
-            dsh[c * 4 + v4] = o4;
-        }
 }
 
 }  // namespace
@@ -540,12 +598,17 @@ extern "C" int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords
     return gsr_check_launch("preprocess_fwd");
 }
 
+extern "C" size_t gsr_preprocess_bwd_workspace_bytes(uint32_t n)
+{
+    return ((size_t)(n ? n : 1) * 12 * sizeof(float) + 255) & ~(size_t)255;
+}
+
 extern "C" int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
                                   const float *rot_raw, const float *opac_raw, const float *sh,
                                   const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
-                                  const uint32_t *pair_pos, const float *pairgrad, float *g_coords,
-                                  float *g_scale, float *g_rot, float *g_opac, float *g_sh, float *g_screen,
-                                  int accumulate, void *stream)
+                                  const float *pairgrad, float *g_coords, float *g_scale, float *g_rot,
+                                  float *g_opac, float *g_sh, float *g_screen, int accumulate, void *workspace,
+                                  size_t workspace_bytes, void *stream)
 {
     ViewK v;
     if (int e = gsr_make_view(view_host, &v)) return e;
@@ -554,15 +617,20 @@ extern "C" int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords
         gsr_set_error("gsr_preprocess_bwd: null pointer");
         return GSR_ERR_ARG;
     }
+    if (!workspace || workspace_bytes < gsr_preprocess_bwd_workspace_bytes((uint32_t)v.n)) {
+        gsr_set_error("gsr_preprocess_bwd: workspace too small");
+        return GSR_ERR_ARG;
+    }
     if (v.n == 0) return GSR_OK;
+    float *gsum = (float *)workspace;
     const dim3 grid(gsr_div_up(v.n, 256)), block(256);
+    hipLaunchKernelGGL(pair_reduce_kernel, grid, block, 0, (hipStream_t)stream, v.n, mask, slot_base, ntiles, pairgrad,
+                       gsum);
     if (accumulate)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, v, coords, scale_raw,
-                           rot_raw, opac_raw, sh, mask, slot_base, ntiles, pair_pos, pairgrad, g_coords, g_scale,
-                           g_rot, g_opac, g_sh, g_screen);
+                           rot_raw, opac_raw, sh, mask, gsum, g_coords, g_scale, g_rot, g_opac, g_sh, g_screen);
     else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, v, coords, scale_raw,
-                           rot_raw, opac_raw, sh, mask, slot_base, ntiles, pair_pos, pairgrad, g_coords, g_scale,
-                           g_rot, g_opac, g_sh, g_screen);
+                           rot_raw, opac_raw, sh, mask, gsum, g_coords, g_scale, g_rot, g_opac, g_sh, g_screen);
     return gsr_check_launch("preprocess_bwd");
 }

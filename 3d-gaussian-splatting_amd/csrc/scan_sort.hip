@@ -123,9 +123,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
 // Stable scatter of one tile.  Wave w owns keys [w*1024, (w+1)*1024) of the tile, item `it` of a
 // wave is the 64 consecutive keys at it*64, so key order = (wave, item, lane).  Ranks inside a
 // wave come from ballots (lanes with an equal digit), per-wave digit counters live in LDS.
+template <typename V>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nb,
+    const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    V *__restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nb,
     const uint32_t *__restrict__ hist_scanned)
 {
     __shared__ uint32_t cnt[SORT_WAVES][RADIX_SIZE];
@@ -221,9 +222,9 @@ extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)
     return hist + gsr_scan_workspace_bytes(nb * RADIX_SIZE);
 }
 
-extern "C" int gsr_sort_pairs(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
-                              uint32_t n, int begin_bit, int end_bit, void *workspace, size_t workspace_bytes,
-                              void *stream)
+template <typename V>
+static int sort_pairs_impl(uint32_t *keys_in, V *vals_in, uint32_t *keys_out, V *vals_out, uint32_t n, int begin_bit,
+                           int end_bit, void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) {
@@ -241,22 +242,39 @@ extern "C" int gsr_sort_pairs(uint32_t *keys_in, uint32_t *vals_in, uint32_t *ke
     const size_t hist_bytes = align256((size_t)nb * RADIX_SIZE * sizeof(uint32_t));
     void *scan_ws = (char *)workspace + hist_bytes;
     const size_t scan_ws_bytes = workspace_bytes - hist_bytes;
-    uint32_t *ki = keys_in, *vi = vals_in, *ko = keys_out, *vo = vals_out;
+    uint32_t *ki = keys_in, *ko = keys_out;
+    V *vi = vals_in, *vo = vals_out;
     bool in_out = false;  // where the current data is: false = the *_in buffers
     for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
         const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
         if (int e = gsr_exclusive_scan(hist, hist, nb * RADIX_SIZE, nullptr, scan_ws, scan_ws_bytes, stream)) return e;
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(SORT_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask,
+        hipLaunchKernelGGL(radix_scatter_kernel<V>, dim3(nb), dim3(SORT_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask,
                            nb, hist);
         uint32_t *t = ki; ki = ko; ko = t;
-        t = vi; vi = vo; vo = t;
+        V *tv = vi; vi = vo; vo = tv;
         in_out = !in_out;
     }
     if (!in_out) {  // even number of passes (or none): the result sits in the *_in buffers
         (void)hipMemcpyAsync(keys_out, keys_in, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
-        (void)hipMemcpyAsync(vals_out, vals_in, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(vals_out, vals_in, (size_t)n * sizeof(V), hipMemcpyDeviceToDevice, st);
     }
     return gsr_check_launch("sort_pairs");
+}
+
+extern "C" int gsr_sort_pairs(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                              uint32_t n, int begin_bit, int end_bit, void *workspace, size_t workspace_bytes,
+                              void *stream)
+{
+    return sort_pairs_impl<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit, workspace,
+                                     workspace_bytes, stream);
+}
+
+extern "C" int gsr_sort_pairs64(uint32_t *keys_in, uint64_t *vals_in, uint32_t *keys_out, uint64_t *vals_out,
+                                uint32_t n, int begin_bit, int end_bit, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    return sort_pairs_impl<uint64_t>(keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit, workspace,
+                                     workspace_bytes, stream);
 }

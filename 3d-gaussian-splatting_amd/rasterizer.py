@@ -101,7 +101,7 @@ def _check_param(name, t, shape_tail, n=None):
 class RenderState:
     """Everything one forward leaves behind for inspection and for the backward."""
     __slots__ = ("view", "cview", "n", "num_visible", "num_pairs", "mask_u8", "pos2d", "cov2d", "radius_full",
-                 "bbox", "ntiles", "rec", "order", "slot_base", "tile_offsets", "pair_pos", "sorted_gauss",
+                 "bbox", "ntiles", "rec", "order", "slot_base", "tile_offsets", "pair_slot", "sorted_gauss",
                  "stream_rec", "final_T", "img", "pairgrad")
 
     def __init__(self):
@@ -159,13 +159,13 @@ def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, vi
     T = ((view.width + view.tile_length - 1) // view.tile_length) * ((view.height + view.tile_length - 1) // view.tile_length)
     I = st.num_pairs
     st.tile_offsets = torch.empty(T + 1, **i32)
-    st.pair_pos = torch.empty(max(I, 1), **i32)
+    st.pair_slot = torch.empty(max(I, 1), **i32)
     st.sorted_gauss = torch.empty(max(I, 1), **i32)
     st.stream_rec = torch.empty(max(I, 1), _lib.REC_FLOATS, **f32)
     ws_bytes = int(lib.gsr_bin_lists_workspace_bytes(I))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _call("gsr_bin_lists", lib.gsr_bin_lists, cv, _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
-                                 _ptr(st.tile_offsets), _ptr(st.pair_pos), _ptr(st.sorted_gauss),
+                                 _ptr(st.tile_offsets), _ptr(st.pair_slot), _ptr(st.sorted_gauss),
                                  _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream)
     st.img = torch.empty(view.width, view.height, 3, **f32)
     st.final_T = torch.empty(view.width, view.height, **f32)
@@ -188,7 +188,8 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
     pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
-    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.final_T),
+    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.pair_slot),
+          _ptr(st.final_T),
                                      _ptr(dimg), I, _ptr(pairgrad), stream)
     st.pairgrad = pairgrad
     if accumulate_into is None:
@@ -199,10 +200,12 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
         grads, acc = accumulate_into, (0 if overwrite else 1)
     if opac_raw.dim() == 1:
         opac_raw = opac_raw.unsqueeze(1)
+    ws_bytes = int(lib.gsr_preprocess_bwd_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _call("gsr_preprocess_bwd", lib.gsr_preprocess_bwd, st.cview, _ptr(coords.contiguous()), _ptr(scale_raw.contiguous()),
                                       _ptr(rot_raw.contiguous()), _ptr(opac_raw.contiguous()), _ptr(sh.contiguous()),
-                                      _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(st.pair_pos),
-                                      _ptr(pairgrad), *[_ptr(g) for g in grads], acc, stream)
+                                      _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles),
+                                      _ptr(pairgrad), *[_ptr(g) for g in grads], acc, _ptr(ws), ws_bytes, stream)
     return grads
 
 

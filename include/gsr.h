@@ -81,19 +81,20 @@ int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const flo
 
 /* Backward of stage 1.  Replaces the autograd graph of the statements listed above
  * (Trainer.py:57).  pairgrad[I,12] holds one gradient record per (tile, Gaussian) pair at the
- * pair's position in the sorted stream; Gaussian g owns emission slots slot_base[g] ..
- * slot_base[g]+ntiles[g], and pair_pos[e] maps slot e to its position.  A Gaussian's records
- * are summed in slot order, so the result is reproducible run to run.
+ * pair's emission slot: Gaussian g owns the contiguous slots slot_base[g] .. slot_base[g]+ntiles[g].
+ * A Gaussian's records are summed in a fixed order, so the result is reproducible run to run.
  * Writes (or, with accumulate != 0, adds to) the dense gradients of the raw parameters
  * g_coords[N,3] g_scale[N,3] g_rot[N,4] g_opac[N] g_sh[N,3,16], and always overwrites
  * g_screen[N,3] (the gradient of this view's screen_coords leaf).  g_sh beyond the active degree,
- * g_screen[:,2] and the rows of culled Gaussians are 0. */
+ * g_screen[:,2] and the rows of culled Gaussians are 0.
+ * workspace: gsr_preprocess_bwd_workspace_bytes(n) (the per-Gaussian sums). */
+size_t gsr_preprocess_bwd_workspace_bytes(uint32_t n);
 int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
                        const float *rot_raw, const float *opac_raw, const float *sh,
                        const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
-                       const uint32_t *pair_pos, const float *pairgrad, float *g_coords,
-                       float *g_scale, float *g_rot, float *g_opac, float *g_sh, float *g_screen,
-                       int accumulate, void *stream);
+                       const float *pairgrad, float *g_coords, float *g_scale, float *g_rot,
+                       float *g_opac, float *g_sh, float *g_screen, int accumulate, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* ---- stage 2: binning and sorting -----------------------------------------------------
  * Replaces Utils/Screen.py:38-62 (tile geometry + membership masks) and the per-tile argsort
@@ -108,6 +109,10 @@ size_t gsr_sort_workspace_bytes(uint32_t n);
 int gsr_sort_pairs(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
                    uint32_t n, int begin_bit, int end_bit, void *workspace, size_t workspace_bytes,
                    void *stream);
+/* The same with 64-bit values (same workspace size). */
+int gsr_sort_pairs64(uint32_t *keys_in, uint64_t *vals_in, uint32_t *keys_out, uint64_t *vals_out,
+                     uint32_t n, int begin_bit, int end_bit, void *workspace, size_t workspace_bytes,
+                     void *stream);
 /* bytes of scratch gsr_exclusive_scan needs */
 size_t gsr_scan_workspace_bytes(uint32_t n);
 /* out[i] = sum(in[0..i)); *total (device, may be NULL) = sum(in[0..n)).  in == out allowed. */
@@ -126,13 +131,14 @@ int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uin
 
 /* Per-tile lists.  num_pairs must be the value read back from counters->num_pairs.
  * Outputs: tile_offsets[T+1] u32 (tile id = yi + n_block_h * xi, Utils/Screen.py:38-39),
- * pair_pos[I] (sorted position of slot e), sorted_gauss[I] (Gaussian index at each sorted
- * position - the concatenated per-tile depth-ordered lists), stream_rec[I,12] (the splat records
- * in that order).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
+ * pair_slot[I] (emission slot of the pair at each sorted position), sorted_gauss[I] (Gaussian
+ * index at each sorted position - the concatenated per-tile depth-ordered lists), stream_rec[I,12]
+ * (the splat records in that order; the sign bit of a record's opacity marks a pair whose alpha is
+ * 0.01 on the whole tile).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
 size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs);
 int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_base, const int32_t *bbox,
                   const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
-                  uint32_t *tile_offsets, uint32_t *pair_pos, uint32_t *sorted_gauss,
+                  uint32_t *tile_offsets, uint32_t *pair_slot, uint32_t *sorted_gauss,
                   float *stream_rec, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- stage 3: compositing -------------------------------------------------------------
@@ -144,10 +150,11 @@ int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets,
                       const float *stream_rec, float *img, float *final_T, void *stream);
 
 /* Backward of the blend (autograd of the statements above).  dimg[W,H,3] is dL/dimg.
- * pairgrad[I,12] is fully overwritten. */
+ * pairgrad[I,12] is fully overwritten; the record of the pair at sorted position p goes to row
+ * pair_slot[p]. */
 int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets,
-                      const float *stream_rec, const float *final_T, const float *dimg,
-                      uint32_t num_pairs, float *pairgrad, void *stream);
+                      const float *stream_rec, const uint32_t *pair_slot, const float *final_T,
+                      const float *dimg, uint32_t num_pairs, float *pairgrad, void *stream);
 
 #ifdef __cplusplus
 }

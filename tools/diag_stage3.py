@@ -20,7 +20,8 @@ st = forward_pipeline(*p, None, view)
 g = backward_pipeline(st, *p, t(cot))
 torch.cuda.synchronize()
 pg = st.pairgrad.cpu().numpy().astype(np.float64)[:st.num_pairs]
-owner = st.sorted_gauss.cpu().numpy()[:st.num_pairs]
+owner = np.zeros(st.num_pairs, np.int64)     # pairgrad rows are in emission-slot order
+owner[st.pair_slot.cpu().numpy()[:st.num_pairs]] = st.sorted_gauss.cpu().numpy()[:st.num_pairs]
 S = np.zeros((n, 12)); np.add.at(S, owner, pg)
 o32 = oracle.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], deg, w, h, tile, a["w2m"], a["proj"], a["cam_pos"], dimg=cot)
 o64 = oracle.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], deg, w, h, tile, a["w2m"], a["proj"], a["cam_pos"], dimg=cot, precise=True)
