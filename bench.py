@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 import gsplat_amd  # noqa: E402,F401
 from gsplat_amd.camera import Camera  # noqa: E402
+from gsplat_amd.minibatch import GradBucket, shard_views  # noqa: E402
 from gsplat_amd.rasterizer import StageTimer, ViewSpec, backward_pipeline, forward_pipeline  # noqa: E402
 from gsplat_amd.scenes import synthetic_scene  # noqa: E402
 
@@ -89,8 +90,7 @@ def main():
     scene = synthetic_scene(n, args.width, args.height, args.sh_degree, seed=0)
     params = [t.to(dev) for t in scene.params()]
     cams = minibatch_cameras(scene, args.views, dev)
-    per_rank = args.views // world
-    my_views = list(range(rank * per_rank, (rank + 1) * per_rank))
+    my_views = shard_views(args.views, world, rank)
     views = [ViewSpec.from_camera(cams[v], args.sh_degree, args.tile) for v in my_views]
     gen = torch.Generator().manual_seed(1)
     # dL/dimg of loss = mean over the minibatch of sum(img * R_v)
@@ -98,12 +98,8 @@ def main():
     cots = [cots[v] for v in my_views]
 
     # one flat fp32 bucket for the five parameter gradients (59 floats per Gaussian)
-    sizes = [3, 3, 4, 1, 48]
-    bucket = torch.zeros(n * sum(sizes), dtype=torch.float32, device=dev)
-    grads, off = [], 0
-    for s_ in sizes:
-        grads.append(bucket[off:off + n * s_].view(n, s_) if s_ != 48 else bucket[off:off + n * s_].view(n, 3, 16))
-        off += n * s_
+    bucket = GradBucket(n, dev)
+    grads = list(bucket.views)
     g_screen = torch.empty(n, 3, dtype=torch.float32, device=dev)
 
     stats = {}
@@ -121,8 +117,7 @@ def main():
                 backward_pipeline(st, *params, cot, accumulate_into=acc, overwrite=True)
             else:
                 backward_pipeline(st, *params, cot, accumulate_into=acc)
-        if world > 1:
-            dist.all_reduce(bucket)
+        bucket.all_reduce()
 
     def sync():
         if world > 1:
