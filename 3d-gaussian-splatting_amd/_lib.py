@@ -59,6 +59,11 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built (run `make -C {CSRC}` or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # libgsr.so needs libamdhip64.so.7.  PyTorch ships its own copy of that runtime; the device
+    # pointers and streams handed to the library come from torch, so both must share ONE runtime.
+    # Importing torch first makes the dynamic loader resolve the soname to torch's copy (a second
+    # runtime loaded from /opt/rocm ahead of torch's reports "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name in SYMBOLS:
         if not hasattr(lib, name):
