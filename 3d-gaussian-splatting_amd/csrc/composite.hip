@@ -22,6 +22,7 @@ constexpr float kAlphaMax = 0.99f;
 // Below this transmittance a pixel's remaining entries cannot change any fp32 result; the
 // backward stops dividing there (see composite_bwd_kernel).
 constexpr float kTinyT = 1e-20f;
+constexpr uint32_t kTouchAhead = 16;   // records (768 bytes) between the L2 touch and the scalar fetch
 
 struct WaveGeom {
     int tile, x, y0;     // pixel column and first row of this lane
@@ -101,6 +102,19 @@ __device__ inline void rec_wait(Rec &R, uint32_t &slot)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(slot)::"memory");
 }
 
+// Pulls the cache lines of a record some entries further on into L2 with a vector load whose
+// result is never used: lanes alternate between the record's first and last dword (byte offsets 0
+// and 44).  Issued once per two entries (96 bytes of stream), the touched addresses are at most 52
+// bytes apart, so every 64-byte line of the stream is touched and no address leaves a record.
+// The scalar record loads then hit L2 instead of waiting for HBM; a wave has only one record in
+// flight, so HBM latency would otherwise bound the stream rate.  `sink` must stay live until the
+// wave drains its vector loads (l2_touch_drain).
+__device__ inline void l2_touch(const float *p, uint32_t lane_off, float &sink)
+{
+    asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(lane_off), "s"(p) : "memory");
+}
+__device__ inline void l2_touch_drain(float &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
+
 // The list builder sets the sign bit of the opacity when alpha is pinned at 0.01 on every pixel of
 // the tile (wave-uniform: a scalar compare and branch).
 __device__ inline bool rec_all_clamped_low(const Rec &R) { return __float_as_int(R_o(R)) < 0; }
@@ -159,6 +173,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
             T[h] = T[h] * (splat(1.0f) - a);   // same rounding as the reference's cumprod of (1 - alpha)
         }
     };
+    const uint32_t touch_off = (threadIdx.x & 1) * 44u;
+    float sink = 0.0f;
     if (w.begin < w.end) {
         // two record buffers, alternating: while one is blended the other is in flight
         const uint32_t last = w.end - 1;
@@ -168,6 +184,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         for (;;) {
             rec_wait(A);
             rec_request(stream_rec, min(k + 1, last), B);
+            l2_touch(stream_rec + (size_t)min(k + kTouchAhead, last) * GSR_REC_FLOATS, touch_off, sink);
             blend(A);
             if (++k >= w.end) break;
             rec_wait(B);
@@ -177,6 +194,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         }
         rec_wait(A);   // nothing may be in flight when the wave ends
         rec_wait(B);
+        l2_touch_drain(sink);
     }
     if (!w.vx) return;
 #pragma unroll
@@ -190,61 +208,100 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     }
 }
 
-// Sum over the 64 lanes with DPP row operations; the total lands in lane 63.
-template <int CTRL, int ROW_MASK>
+// ---- wave reductions of the gradient sums ------------------------------------------------------
+// Nine sums per entry have to be taken over the 64 lanes.  A plain butterfly costs six
+// cross-lane adds per value.  Here values are MERGED while they are reduced: one
+// v_permlane32_swap (gfx950) exchanges the upper half of one register with the lower half of
+// another, so a single add afterwards reduces two values by one level and leaves them in one
+// register (one value per half-wave); v_permlane16_swap does the same one level down (one value
+// per 16-lane row), a bank-masked DPP move once more (one value per 8 lanes).  Eight values end up
+// in ONE register and share the last three butterfly steps.
+
+template <int CTRL>
 __device__ inline float dpp_add(float val)
 {
-    // lanes the control or the row mask leaves without a source receive 0
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(val), CTRL, ROW_MASK, 0xF, false);
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(val), CTRL, 0xF, 0xF, false);
     return val + __int_as_float(moved);
 }
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
 
-// Row-broadcast steps of the wave reduction.  hipcc fuses a DPP move into a float add only for full
-// row masks, so these two steps are written as the single instruction they are.  DPP reads need two
-// wait states after the VALU write of their source: one s_nop 1 ahead of each group; inside a
-// group consecutive instructions touch different registers.
-#define GSR_BCAST3(ctrl, mask, x)                                                                           \
-    asm volatile("s_nop 1\n\t"                                                                             \
-                 "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
-                 "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:" mask " bank_mask:0xf\n\t"                    \
-                 "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:" mask " bank_mask:0xf"                         \
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]))
-
-// Sums 3*G values (G groups of three) over the 64 lanes; totals land in lane 63.  Each DPP step is
-// applied to all values before the next step starts, so dependent steps are far enough apart.
-template <int N>
-__device__ inline void wave_sum_to_lane63(float (&x)[N])
+// lanes 0..31: a[l] + a[l+32];  lanes 32..63: b[l-32] + b[l]
+__device__ inline float merge_halves(float a, float b)
 {
-    static_assert(N % 3 == 0, "values are reduced in groups of three");
-#pragma unroll
-    for (int c = 0; c < N; ++c) x[c] = dpp_add<0xB1, 0xF>(x[c]);   // quad_perm [1,0,3,2]
-#pragma unroll
-    for (int c = 0; c < N; ++c) x[c] = dpp_add<0x4E, 0xF>(x[c]);   // quad_perm [2,3,0,1]
-#pragma unroll
-    for (int c = 0; c < N; ++c) x[c] = dpp_add<0x141, 0xF>(x[c]);  // row_half_mirror
-#pragma unroll
-    for (int c = 0; c < N; ++c) x[c] = dpp_add<0x140, 0xF>(x[c]);  // row_mirror: every lane holds its row's sum
-#pragma unroll
-    for (int c = 0; c < N; c += 3) { float (&g)[3] = reinterpret_cast<float (&)[3]>(x[c]); GSR_BCAST3("row_bcast:15", "0xa", g); }
-#pragma unroll
-    for (int c = 0; c < N; c += 3) { float (&g)[3] = reinterpret_cast<float (&)[3]>(x[c]); GSR_BCAST3("row_bcast:31", "0xc", g); }
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows (16 lanes) 0..3: a.row0 + a.row1, b.row0 + b.row1, a.row2 + a.row3, b.row2 + b.row3
+__device__ inline float merge_rows(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// in every row: lanes 0..7: a[l] + a[l+8];  lanes 8..15: b[l-8] + b[l]
+__device__ inline float merge_half_rows(float a, float b)
+{
+    const float sa = dpp_add<DPP_ROR8>(a), sb = dpp_add<DPP_ROR8>(b);
+    // identity move of sb into banks 2 and 3 (lanes 8..15 of each row), the rest keeps sa
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(sa), __float_as_int(sb), 0xE4, 0xF, 0xC, false));
+}
+// every lane ends with the sum over its group of 8 (resp. its row of 16)
+__device__ inline float sum8(float x) { return dpp_add<DPP_HALF_MIRROR>(dpp_add<DPP_QUAD_2301>(dpp_add<DPP_QUAD_1032>(x))); }
+__device__ inline float sum16(float x) { return dpp_add<DPP_MIRROR>(sum8(x)); }
+
+// Which lane writes which float of a gradient record, fixed per lane.
+// Full records: group g of 8 lanes (g = lane / 8) holds record float g, row r (r = lane / 16) holds
+// the row's part of the blue sum, record float 8 + r.
+// Colour-only records: after merge_halves(red, green) and merge_rows(.., blue) the rows hold red,
+// blue (rows 0-1), green, blue (rows 2-3): floats 6, 8, 7, 9; the other eight floats are zeros.
+struct RecordLanes {
+    bool full_writer, full_main;   // lane writes a float of a full record / it is one of the 8 merged sums
+    uint32_t full_slot;
+    bool col_writer, col_zero;
+    uint32_t col_slot;
+};
+__device__ inline RecordLanes record_lanes(int lane)
+{
+    RecordLanes L;
+    L.full_main = (lane & 7) == 0;
+    L.full_writer = L.full_main || (lane & 15) == 1;
+    L.full_slot = L.full_main ? (uint32_t)(lane >> 3) : 8u + (uint32_t)(lane >> 4);
+    L.col_zero = lane < 6 || lane == 10 || lane == 11;
+    L.col_writer = L.col_zero || lane == 6 || lane == 24 || lane == 39 || lane == 57;
+    L.col_slot = (uint32_t)(lane & 15);
+    return L;
 }
 
-// One gradient record: plain stores when a single wave owns the tile, float atomics otherwise.
 template <bool ATOMIC>
-__device__ inline void store_pairgrad(float *dst, float v0, float v1, float v2, float v3, float v4, float v5, float v6,
-                                      float v7, float v8)
+__device__ inline void put_record_float(float *dst, float val)
 {
     if (ATOMIC) {
-        const float v[9] = {v0, v1, v2, v3, v4, v5, v6, v7, v8};
-#pragma unroll
-        for (int c = 0; c < 9; ++c)
-            if (v[c] != 0.0f) atomicAdd(dst + c, v[c]);
+        if (val != 0.0f) atomicAdd(dst, val);   // several waves share the record; it was zeroed by the launcher
     } else {
-        reinterpret_cast<float4 *>(dst)[0] = make_float4(v0, v1, v2, v3);
-        reinterpret_cast<float4 *>(dst)[1] = make_float4(v4, v5, v6, v7);
-        reinterpret_cast<float4 *>(dst)[2] = make_float4(v8, 0.0f, 0.0f, 0.0f);
+        *dst = val;
     }
+}
+
+// Full record, floats: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2, dL/d(opacity),
+// dL/d(red), dL/d(green), then four partial sums of dL/d(blue).
+template <bool ATOMIC>
+__device__ inline void reduce_store_full(const RecordLanes &L, float *dst, float vx, float vy, float xx, float xy,
+                                         float yy, float o, float r, float g, float b)
+{
+    // pairing order chosen so that group g of 8 lanes ends up with record float g
+    const float m0 = merge_halves(vx, yy), m1 = merge_halves(xx, r), m2 = merge_halves(vy, o), m3 = merge_halves(xy, g);
+    const float n0 = merge_rows(m0, m1);   // rows: vx, xx, yy, r
+    const float n1 = merge_rows(m2, m3);   // rows: vy, xy, o,  g
+    const float all8 = sum8(merge_half_rows(n0, n1));
+    const float blue = sum16(b);
+    if (L.full_writer) put_record_float<ATOMIC>(dst + L.full_slot, L.full_main ? all8 : blue);
+}
+
+// Colour-only record (the clamp blocks every other gradient of the entry).
+template <bool ATOMIC>
+__device__ inline void reduce_store_colour(const RecordLanes &L, float *dst, float r, float g, float b)
+{
+    const float rows = sum16(merge_rows(merge_halves(r, g), b));   // rows: red, blue(0-1), green, blue(2-3)
+    if (L.col_writer) put_record_float<ATOMIC>(dst + L.col_slot, L.col_zero ? 0.0f : rows);
 }
 
 // Reverse sweep of one list for the 4 pixels of a lane.  CHECK: pixel j only takes part in
@@ -256,7 +313,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
                                  const uint32_t *__restrict__ pair_slot, float *__restrict__ pairgrad)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
-    const int lane = threadIdx.x & 63;
+    const RecordLanes lanes = record_lanes(threadIdx.x & 63);
     auto entry = [&](const Rec &R, uint32_t k, uint32_t slot) {
         float *dst = pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS;   // a Gaussian's records are contiguous
         if (rec_all_clamped_low(R)) {
@@ -286,9 +343,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
                 c_g = pk_fma(wgt, gg[h], c_g);
                 c_b = pk_fma(wgt, gb[h], c_b);
             }
-            float col[3] = {c_r.x + c_r.y, c_g.x + c_g.y, c_b.x + c_b.y};
-            wave_sum_to_lane63(col);
-            if (lane == 63) store_pairgrad<ATOMIC>(dst, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, col[0], col[1], col[2]);
+            reduce_store_colour<ATOMIC>(lanes, dst, c_r.x + c_r.y, c_g.x + c_g.y, c_b.x + c_b.y);
             return;
         }
         const float dx = R_gx(R) - pxf;
@@ -351,26 +406,24 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             s_yy = pk_fma(hvy, vy, s_yy);
         }
         const bool any_geom = __ballot(any_pass) != 0ull;
-        if (any_geom) {
-            float val[9] = {s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y, s_yy.x + s_yy.y,
-                            s_o.x + s_o.y,   s_r.x + s_r.y,   s_g.x + s_g.y,   s_b.x + s_b.y};
-            wave_sum_to_lane63(val);
-            if (lane == 63)
-                store_pairgrad<ATOMIC>(dst, val[0], val[1], val[2], val[3], val[4], val[5], val[6], val[7], val[8]);
-        } else {
-            float col[3] = {s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y};
-            wave_sum_to_lane63(col);
-            if (lane == 63) store_pairgrad<ATOMIC>(dst, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, col[0], col[1], col[2]);
-        }
+        if (any_geom)
+            reduce_store_full<ATOMIC>(lanes, dst, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
+                                      s_yy.x + s_yy.y, s_o.x + s_o.y, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+        else
+            reduce_store_colour<ATOMIC>(lanes, dst, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
     };
     // back to front, two record buffers alternating (see composite_fwd_kernel)
     uint32_t k = w.end - 1;   // the caller guarantees a non-empty list
     Rec A, B;
     uint32_t sa, sb;
+    const uint32_t touch_off = (threadIdx.x & 1) * 44u;
+    float sink = 0.0f;
     rec_request(stream_rec, pair_slot, k, A, sa);
     for (;;) {
         rec_wait(A, sa);
         rec_request(stream_rec, pair_slot, k > w.begin ? k - 1 : k, B, sb);
+        l2_touch(stream_rec + (size_t)(k - w.begin > kTouchAhead ? k - kTouchAhead : w.begin) * GSR_REC_FLOATS,
+                 touch_off, sink);
         entry(A, k, sa);
         if (k == w.begin) break;
         --k;
@@ -382,6 +435,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     }
     rec_wait(A, sa);
     rec_wait(B, sb);
+    l2_touch_drain(sink);
 }
 
 // ATOMIC = several waves share a tile (L > 16): their sums meet in pairgrad through float atomics
@@ -396,7 +450,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
 {
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, w)) return;
-    if (w.begin == w.end) return;
+    if (w.begin >= w.end) return;
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], gr[2], gg[2], gb[2];
     bool tiny = false;

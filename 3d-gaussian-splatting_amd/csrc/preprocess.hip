@@ -306,7 +306,8 @@ __device__ inline void put(float *dst, float v)
     if (ACC) *dst += v; else *dst = v;
 }
 
-// Sum of each Gaussian's per-tile gradient records -> gsum[N,12] (9 used).  The records of
+// Sum of each Gaussian's per-tile gradient records -> gsum[N,12] (9 used; the last four floats of a
+// record are partial sums of one quantity).  The records of
 // Gaussian g are the contiguous slots slot_base[g] .. slot_base[g]+ntiles[g] of pairgrad.  One
 // thread per Gaussian walks its slots in order; a Gaussian with many tiles is summed by the whole
 // wave (strided partial sums, then a fixed butterfly), so one huge splat cannot serialise thousands
@@ -316,10 +317,10 @@ constexpr uint32_t kHeavyTiles = 96;
 __device__ inline void add_record(double (&acc)[9], const float *__restrict__ pairgrad, uint32_t slot)
 {
     const float4 *src = reinterpret_cast<const float4 *>(pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS);
-    const float4 a = src[0], b = src[1];
-    const float c8 = pairgrad[(size_t)slot * GSR_PAIRGRAD_FLOATS + 8];
+    const float4 a = src[0], b = src[1], c = src[2];
     acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c8;
+    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    acc[8] += ((double)c.x + (double)c.y) + ((double)c.z + (double)c.w);   // blue arrives as four partial sums
 }
 
 __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, const uint8_t *__restrict__ mask,

@@ -58,8 +58,8 @@ typedef struct gsr_counters {
 #define GSR_REC_FLOATS 12
 /* Per-(tile,Gaussian) gradient record produced by the compositing backward. */
 /* With h = -2 dL/d(exponent) per pixel, d = centre - pixel and v = inverse covariance * d:
- * sum h v_x, sum h v_y, sum h v_x v_x, sum h v_x v_y, sum h v_y v_y, dL/d(opacity), dL/d(r,g,b),
- * pad x3 */
+ * sum h v_x, sum h v_y, sum h v_x v_x, sum h v_x v_y, sum h v_y v_y, dL/d(opacity), dL/d(r), dL/d(g),
+ * then FOUR partial sums whose total is dL/d(b) */
 #define GSR_PAIRGRAD_FLOATS 12
 
 const char *gsr_last_error(void);

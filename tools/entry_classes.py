@@ -1,0 +1,49 @@
+"""Fractions of list entries by the path the compositing backward takes for them (bench scene)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gsplat_amd  # noqa
+from gsplat_amd.rasterizer import ViewSpec, forward_pipeline
+from gsplat_amd.scenes import synthetic_scene
+dev = torch.device("cuda:0")
+W, H = 1920, 1080
+sc = synthetic_scene(1000000, W, H, 3, 0)
+p = [t.to(dev) for t in sc.params()]
+st = forward_pipeline(*p, None, ViewSpec.from_camera(sc.camera(device=dev), 3, 16))
+off = st.tile_offsets.cpu().long()
+nbh = (H + 15) // 16
+g = torch.Generator().manual_seed(0)
+tiles = torch.randint(0, off.numel() - 1, (200,), generator=g).tolist()
+tot = flagged = geom = nongeom = 0
+npass = []
+runs = []
+for t in tiles:
+    b, e = int(off[t]), int(off[t + 1])
+    if e <= b: continue
+    r = st.stream_rec[b:e]
+    xi, yi = t // nbh, t % nbh
+    xs = torch.arange(xi * 16, min(xi * 16 + 16, W), device=dev).float()
+    ys = torch.arange(yi * 16, min(yi * 16 + 16, H), device=dev).float()
+    dx = r[:, 0, None, None] - xs[None, :, None]
+    dy = r[:, 1, None, None] - ys[None, None, :]
+    q = r[:, 2, None, None] * dx * dx + r[:, 3, None, None] * dx * dy + r[:, 4, None, None] * dy * dy
+    raw = r[:, 5].abs()[:, None, None] * torch.exp2(q)
+    ps = ((raw >= 0.01) & (raw <= 0.99)).flatten(1)
+    anyp = ps.any(1)
+    fl = r[:, 5] < 0
+    tot += e - b; flagged += int(fl.sum()); geom += int((~fl & anyp).sum()); nongeom += int((~fl & ~anyp).sum())
+    npass.append(ps[~fl & anyp].float().sum(1))
+    f = fl.cpu().tolist(); k = 0
+    while k < len(f):
+        if f[k]:
+            j = k
+            while j < len(f) and f[j]: j += 1
+            runs.append(j - k); k = j
+        else: k += 1
+npass = torch.cat(npass)
+print("entries %d: flagged %.3f  geometric %.3f  clamped everywhere but not flagged %.3f" % (tot, flagged / tot, geom / tot, nongeom / tot))
+print("geometric entries: passing pixels of 256: mean %.1f median %.0f; <=16 px: %.3f, <=64 px: %.3f" % (
+    npass.mean(), npass.median(), (npass <= 16).float().mean(), (npass <= 64).float().mean()))
+runs = torch.tensor(runs).float()
+print("flagged runs: mean length %.2f, entries in runs >= 2: %.3f, >= 4: %.3f" % (runs.mean(), runs[runs >= 2].sum() / runs.sum(), runs[runs >= 4].sum() / runs.sum()))
