@@ -91,8 +91,9 @@ __device__ inline bool tile_all_clamped_low(float gx, float gy, float A, float B
 }
 
 // One thread per sorted position p: copy the owner's splat record into the stream, note the
-// owner and its emission slot, mark tile boundaries, and flag (sign bit of the opacity) records
-// whose alpha is 0.01 on the whole tile so the compositing kernels can skip their exponentials.
+// owner and its emission slot, mark tile boundaries, and flag the halves of the tile's block on
+// which alpha is 0.01 everywhere (sign bit of the opacity: top 8 rows, sign bit of the red
+// colour: bottom 8 rows) so the compositing kernels can skip their exponentials there.
 __global__ __launch_bounds__(256) void finalize_lists_kernel(
     ViewK v, const uint32_t *__restrict__ sorted_tile, const uint64_t *__restrict__ sorted_owner_slot,
     const float *__restrict__ rec, uint32_t num_pairs, uint32_t T, uint32_t *__restrict__ tile_offsets,
@@ -112,7 +113,17 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
         const int xi = (int)(cur / (uint32_t)v.nbh), yi = (int)(cur - (uint32_t)xi * v.nbh);
         const float x0 = (float)(xi * v.L), y0 = (float)(yi * v.L);
         const float x1 = (float)(min((xi + 1) * v.L, v.W) - 1), y1 = (float)(min((yi + 1) * v.L, v.H) - 1);
-        if (tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, y1)) b.y = -b.y;
+        bool low_top, low_bottom;
+        if (v.L == 16) {
+            // one compositing wave per tile: the halves of its 16x16 block are tested separately
+            const float ym = y0 + 7.0f;
+            low_top = tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, fminf(ym, y1));
+            low_bottom = ym >= y1 || tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, ym + 1.0f, y1);
+        } else {
+            low_top = low_bottom = tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, y1);
+        }
+        if (low_top) b.y = -b.y;      // opacity >= 0 ...
+        if (low_bottom) b.z = -b.z;   // ... and red = max(. + 0.5, 0) >= 0, so both sign bits are free
     }
     dst[0] = a; dst[1] = b; dst[2] = c;
     const uint32_t first = p == 0 ? 0u : sorted_tile[p - 1] + 1u;

@@ -1,8 +1,10 @@
 // Stage 3: per-tile front-to-back blend and its backward.
 //
 // Work decomposition (CDNA4): one 64-lane wave owns one 16x16 pixel block, 4 pixels per lane
-// (lane -> column x = lane/4, rows y0..y0+3 with y0 = 4*(lane%4); y is the fast image axis, so
-// a lane's pixels are 12 contiguous floats of the image).  A reference tile of edge L is covered
+// (lane -> column x = lane/4, rows y0, y0+4, y0+8, y0+12 with y0 = lane%4).  The lane's first two
+// pixels lie in the top 8 rows of the block and the other two in the bottom 8 rows; each pair is
+// processed with packed fp32 instructions, and a pair is the unit of the clamped-low fast path
+// (see rec_low_top / rec_low_bottom).  A reference tile of edge L is covered
 // by ceil(L/16)^2 such waves, all streaming the tile's list.  The list is a contiguous stream of
 // 48-byte splat records in depth order; the record address is wave-uniform, so records are
 // fetched with scalar loads into SGPRs and broadcast to the vector ALU for free - no LDS
@@ -25,7 +27,7 @@ constexpr float kTinyT = 1e-20f;
 constexpr uint32_t kTouchAhead = 16;   // records (768 bytes) between the L2 touch and the scalar fetch
 
 struct WaveGeom {
-    int tile, x, y0;     // pixel column and first row of this lane
+    int tile, x, y0;     // pixel column and first row of this lane; its rows are y0 + 4 j, j = 0..3
     bool vx;             // column inside the tile and the image
     int ylim;            // rows < ylim are inside
     uint32_t begin, end; // list range (wave-uniform)
@@ -45,7 +47,7 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
     const int lane = threadIdx.x & 63;
     w.tile = (int)tile;
     w.x = xi * v.L + sxi * 16 + (lane >> 2);
-    w.y0 = yi * v.L + syi * 16 + (lane & 3) * 4;
+    w.y0 = yi * v.L + syi * 16 + (lane & 3);
     const int xlim = min((xi + 1) * v.L, v.W);
     w.ylim = min((yi + 1) * v.L, v.H);
     w.vx = w.x < xlim;
@@ -86,6 +88,7 @@ __device__ inline void rec_request(const float *__restrict__ stream_rec, uint32_
 }
 __device__ inline void rec_wait(Rec &R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b)::"memory"); }
 
+
 // The same plus the record's emission slot (where its gradient record goes), for the backward.
 __device__ inline void rec_request(const float *__restrict__ stream_rec, const uint32_t *__restrict__ pair_slot,
                                    uint32_t k, Rec &R, uint32_t &slot)
@@ -115,9 +118,15 @@ __device__ inline void l2_touch(const float *p, uint32_t lane_off, float &sink)
 }
 __device__ inline void l2_touch_drain(float &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
 
-// The list builder sets the sign bit of the opacity when alpha is pinned at 0.01 on every pixel of
-// the tile (wave-uniform: a scalar compare and branch).
-__device__ inline bool rec_all_clamped_low(const Rec &R) { return __float_as_int(R_o(R)) < 0; }
+// The list builder marks, per record, the halves of the 16x16 block on which alpha is pinned at
+// 0.01 for every pixel: sign bit of the opacity = top 8 rows, sign bit of the red colour = bottom 8
+// rows (both values are >= 0 by construction; read them through rec_opacity / rec_red).  For tiles larger than one block both bits describe the whole
+// tile.  Wave-uniform: scalar compares and branches.
+__device__ inline bool rec_low_top(const Rec &R) { return __float_as_int(R_o(R)) < 0; }
+__device__ inline bool rec_low_bottom(const Rec &R) { return __float_as_int(R_r(R)) < 0; }
+__device__ inline float strip_sign(float x) { return __int_as_float(__float_as_int(x) & 0x7fffffff); }
+__device__ inline float rec_opacity(const Rec &R) { return strip_sign(R_o(R)); }
+__device__ inline float rec_red(const Rec &R) { return strip_sign(R_r(R)); }
 
 __device__ inline float clamp_alpha(float raw) { return fminf(fmaxf(raw, kAlphaMin), kAlphaMax); }
 
@@ -137,41 +146,48 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, w)) return;
     const float pxf = (float)w.x;
-    f2 pyf[2], T[2], cr[2], cg[2], cb[2];   // pixel rows (y0, y0+1) and (y0+2, y0+3)
+    f2 pyf[2], T[2], cr[2], cg[2], cb[2];   // pixel rows (y0, y0+4): top half, (y0+8, y0+12): bottom half
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        pyf[h] = f2{(float)(w.y0 + 2 * h), (float)(w.y0 + 2 * h + 1)};
+        pyf[h] = f2{(float)(w.y0 + 8 * h), (float)(w.y0 + 8 * h + 4)};
         T[h] = splat(1.0f);
         cr[h] = cg[h] = cb[h] = splat(0.0f);
     }
 
+    // alpha is 0.01 on this half of the block: no exponent, no exp
+    auto half_low = [&](int h, const Rec &R, float red) {
+        const f2 wgt = splat(kAlphaMin) * T[h];
+        cr[h] = pk_fma(wgt, splat(red), cr[h]);
+        cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
+        cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
+        T[h] = T[h] * splat(1.0f - kAlphaMin);
+    };
+    auto half_full = [&](int h, const Rec &R, float red, float o, float bdx, float adx2) {
+        const f2 dy = splat(R_gy(R)) - pyf[h];
+        const f2 q = pk_fma(pk_fma(splat(R_D(R)), dy, splat(bdx)), dy, splat(adx2));
+        const f2 a = clamp_alpha2(splat(o) * exp2_2(q));
+        const f2 wgt = a * T[h];
+        cr[h] = pk_fma(wgt, splat(red), cr[h]);
+        cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
+        cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
+        T[h] = T[h] * (splat(1.0f) - a);   // same rounding as the reference's cumprod of (1 - alpha)
+    };
     auto blend = [&](const Rec &R) {
-        if (rec_all_clamped_low(R)) {
-            // alpha is 0.01 on the whole tile: no exponent, no exp
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f2 wgt = splat(kAlphaMin) * T[h];
-                cr[h] = pk_fma(wgt, splat(R_r(R)), cr[h]);
-                cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
-                cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
-                T[h] = T[h] * splat(1.0f - kAlphaMin);
-            }
+        const bool low0 = rec_low_top(R), low1 = rec_low_bottom(R);
+        const float red = rec_red(R);
+        if (low0 && low1) {
+            half_low(0, R, red);
+            half_low(1, R, red);
             return;
         }
+        const float o = rec_opacity(R);
         const float dx = R_gx(R) - pxf;
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f2 dy = splat(R_gy(R)) - pyf[h];
-            const f2 q = pk_fma(pk_fma(splat(R_D(R)), dy, splat(bdx)), dy, splat(adx2));
-            const f2 a = clamp_alpha2(splat(R_o(R)) * exp2_2(q));
-            const f2 wgt = a * T[h];
-            cr[h] = pk_fma(wgt, splat(R_r(R)), cr[h]);
-            cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
-            cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
-            T[h] = T[h] * (splat(1.0f) - a);   // same rounding as the reference's cumprod of (1 - alpha)
-        }
+        // (the forward pass is bound by the rate of the scalar record fetches, not by arithmetic:
+        // treating a single clamped-low half separately only adds branches here)
+        half_full(0, R, red, o, bdx, adx2);
+        half_full(1, R, red, o, bdx, adx2);
     };
     const uint32_t touch_off = (threadIdx.x & 1) * 44u;
     float sink = 0.0f;
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     if (!w.vx) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int y = w.y0 + j;
+        const int y = w.y0 + 4 * j;
         if (y < w.ylim) {
             const size_t pix = (size_t)w.x * v.H + y;
             img[pix * 3 + 0] = cr[j >> 1][j & 1]; img[pix * 3 + 1] = cg[j >> 1][j & 1]; img[pix * 3 + 2] = cb[j >> 1][j & 1];
@@ -313,97 +329,116 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
                                  const uint32_t *__restrict__ pair_slot, float *__restrict__ pairgrad)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
+    const f2 py_top = pyf[0];
     const RecordLanes lanes = record_lanes(threadIdx.x & 63);
+    // Sums of one entry over the lane's pixels (pairs are added up at the end).
+    f2 s_vx, s_vy, s_xx, s_xy, s_yy, s_o, s_r, s_g, s_b;
+    bool any_pass;
+
+    // One half of the block with alpha = 0.01 on every pixel: only the transmittance recurrence, the
+    // colour sums and the suffix remain; the clamp blocks every geometric gradient.
+    auto half_low = [&](int h, const Rec &R, uint32_t k, float red) {
+        const float om = 1.0f - kAlphaMin, rcp = 1.0f / (1.0f - kAlphaMin);
+        const f2 t0 = T[h] * splat(rcp);
+        f2 Tk = pk_fma(pk_fma(splat(-om), t0, T[h]), splat(rcp), t0);
+        f2 wgt = splat(kAlphaMin) * Tk;
+        const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(red) * gr[h]));
+        f2 suf = pk_fma(wgt, cgd, suffix[h]);
+        if (CHECK) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool on = (k - w.begin) < nstop[2 * h + e];
+                Tk[e] = on ? Tk[e] : T[h][e];
+                suf[e] = on ? suf[e] : suffix[h][e];
+                wgt[e] = on ? wgt[e] : 0.0f;
+            }
+        }
+        T[h] = Tk;
+        suffix[h] = suf;
+        s_r = pk_fma(wgt, gr[h], s_r);
+        s_g = pk_fma(wgt, gg[h], s_g);
+        s_b = pk_fma(wgt, gb[h], s_b);
+    };
+    auto half_full = [&](int h, const Rec &R, uint32_t k, float red, float o, float dx, float adx2, float bdx) {
+        const float cadx = R_ca(R) * dx;   // with v = conic * d:  v_x = a dx + bh dy,  v_y = bh dx + d dy
+        const float cbdx = R_cbh(R) * dx;
+        // bottom-half rows are the top-half rows + 8 (exact in fp32): one register pair less to keep
+        const f2 dy = splat(R_gy(R)) - (h == 0 ? py_top : py_top + splat(8.0f));
+        const f2 q = pk_fma(pk_fma(splat(R_D(R)), dy, splat(bdx)), dy, splat(adx2));
+        const f2 G = exp2_2(q);
+        const f2 raw = splat(o) * G;
+        const f2 a = clamp_alpha2(raw);
+        // T_k = T_{k+1} / (1 - a), correctly rounded: quotient estimate, exact remainder (fma), one
+        // correction.  A plain T * rcp(1 - a) is not good enough here: most entries of a long list
+        // have the same a (0.01), so the reciprocal's rounding error repeats with the same sign
+        // at every step and the transmittance drifts by ~1e-4 over a few thousand entries.
+        const f2 om = splat(1.0f) - a;
+        const f2 rcp = f2{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+        const f2 t0 = T[h] * rcp;
+        f2 Tk = pk_fma(pk_fma(-om, t0, T[h]), rcp, t0);   // transmittance in front of this entry
+        f2 wgt = a * Tk;
+        const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(red) * gr[h]));
+        f2 d_a = pk_fma(Tk, cgd, -(suffix[h] * rcp));
+        f2 suf = pk_fma(wgt, cgd, suffix[h]);
+        if (CHECK) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool on = (k - w.begin) < nstop[2 * h + e];
+                Tk[e] = on ? Tk[e] : T[h][e];
+                suf[e] = on ? suf[e] : suffix[h][e];
+                wgt[e] = on ? wgt[e] : 0.0f;
+                d_a[e] = on ? d_a[e] : 0.0f;
+            }
+        }
+        T[h] = Tk;
+        suffix[h] = suf;
+        s_r = pk_fma(wgt, gr[h], s_r);
+        s_g = pk_fma(wgt, gg[h], s_g);
+        s_b = pk_fma(wgt, gb[h], s_b);
+        // clamp passes gradient on [0.01, 0.99]: exactly when the clamped value equals the input
+        const bool p0 = (a.x == raw.x), p1 = (a.y == raw.y);
+        any_pass |= p0 | p1;
+        const f2 d_raw = f2{p0 ? d_a.x : 0.0f, p1 ? d_a.y : 0.0f};
+        s_o = pk_fma(d_raw, G, s_o);
+        const f2 hh = d_raw * a;                       // = -2 dL/d(exponent); a == raw when it matters
+        // Sums are taken in the conic-weighted coordinates v: summing h*d and weighting by the
+        // conic afterwards would cancel large coherent sums for elongated Gaussians.
+        const f2 vx = pk_fma(splat(R_cbh(R)), dy, splat(cadx));
+        const f2 vy = pk_fma(splat(R_cd(R)), dy, splat(cbdx));
+        const f2 hvx = hh * vx, hvy = hh * vy;
+        s_vx += hvx;
+        s_vy += hvy;
+        s_xx = pk_fma(hvx, vx, s_xx);
+        s_xy = pk_fma(hvx, vy, s_xy);
+        s_yy = pk_fma(hvy, vy, s_yy);
+    };
     auto entry = [&](const Rec &R, uint32_t k, uint32_t slot) {
         float *dst = pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS;   // a Gaussian's records are contiguous
-        if (rec_all_clamped_low(R)) {
-            // alpha = 0.01 on every pixel: only the transmittance recurrence, the colour sums and the
-            // suffix remain; the clamp blocks every geometric gradient
-            const float om = 1.0f - kAlphaMin, rcp = 1.0f / (1.0f - kAlphaMin);
-            f2 c_r = splat(0.f), c_g = splat(0.f), c_b = splat(0.f);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f2 t0 = T[h] * splat(rcp);
-                f2 Tk = pk_fma(pk_fma(splat(-om), t0, T[h]), splat(rcp), t0);
-                f2 wgt = splat(kAlphaMin) * Tk;
-                const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(R_r(R)) * gr[h]));
-                f2 suf = pk_fma(wgt, cgd, suffix[h]);
-                if (CHECK) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const bool on = (k - w.begin) < nstop[2 * h + e];
-                        Tk[e] = on ? Tk[e] : T[h][e];
-                        suf[e] = on ? suf[e] : suffix[h][e];
-                        wgt[e] = on ? wgt[e] : 0.0f;
-                    }
-                }
-                T[h] = Tk;
-                suffix[h] = suf;
-                c_r = pk_fma(wgt, gr[h], c_r);
-                c_g = pk_fma(wgt, gg[h], c_g);
-                c_b = pk_fma(wgt, gb[h], c_b);
-            }
-            reduce_store_colour<ATOMIC>(lanes, dst, c_r.x + c_r.y, c_g.x + c_g.y, c_b.x + c_b.y);
+        const bool low0 = rec_low_top(R), low1 = rec_low_bottom(R);
+        const f2 z = splat(0.f);
+        s_r = s_g = s_b = z;
+        const float red = rec_red(R);
+        if (low0 && low1) {
+            half_low(0, R, k, red);
+            half_low(1, R, k, red);
+            reduce_store_colour<ATOMIC>(lanes, dst, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
             return;
         }
+        s_vx = s_vy = s_xx = s_xy = s_yy = s_o = z;
+        any_pass = false;
+        const float o = rec_opacity(R);
         const float dx = R_gx(R) - pxf;
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
-        const float cadx = R_ca(R) * dx;   // with v = conic * d:  v_x = a dx + bh dy,  v_y = bh dx + d dy
-        const float cbdx = R_cbh(R) * dx;
-        const f2 z = splat(0.f);
-        f2 s_vx = z, s_vy = z, s_xx = z, s_xy = z, s_yy = z, s_o = z, s_r = z, s_g = z, s_b = z;
-        bool any_pass = false;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f2 dy = splat(R_gy(R)) - pyf[h];
-            const f2 q = pk_fma(pk_fma(splat(R_D(R)), dy, splat(bdx)), dy, splat(adx2));
-            const f2 G = exp2_2(q);
-            const f2 raw = splat(R_o(R)) * G;
-            const f2 a = clamp_alpha2(raw);
-            // T_k = T_{k+1} / (1 - a), correctly rounded: quotient estimate, exact remainder (fma), one
-            // correction.  A plain T * rcp(1 - a) is not good enough here: most entries of a long list
-            // have the same a (0.01), so the reciprocal's rounding error repeats with the same sign
-            // at every step and the transmittance drifts by ~1e-4 over a few thousand entries.
-            const f2 om = splat(1.0f) - a;
-            const f2 rcp = f2{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-            const f2 t0 = T[h] * rcp;
-            f2 Tk = pk_fma(pk_fma(-om, t0, T[h]), rcp, t0);   // transmittance in front of this entry
-            f2 wgt = a * Tk;
-            const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(R_r(R)) * gr[h]));
-            f2 d_a = pk_fma(Tk, cgd, -(suffix[h] * rcp));
-            f2 suf = pk_fma(wgt, cgd, suffix[h]);
-            if (CHECK) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const bool on = (k - w.begin) < nstop[2 * h + e];
-                    Tk[e] = on ? Tk[e] : T[h][e];
-                    suf[e] = on ? suf[e] : suffix[h][e];
-                    wgt[e] = on ? wgt[e] : 0.0f;
-                    d_a[e] = on ? d_a[e] : 0.0f;
-                }
-            }
-            T[h] = Tk;
-            suffix[h] = suf;
-            s_r = pk_fma(wgt, gr[h], s_r);
-            s_g = pk_fma(wgt, gg[h], s_g);
-            s_b = pk_fma(wgt, gb[h], s_b);
-            // clamp passes gradient on [0.01, 0.99]: exactly when the clamped value equals the input
-            const bool p0 = (a.x == raw.x), p1 = (a.y == raw.y);
-            any_pass |= p0 | p1;
-            const f2 d_raw = f2{p0 ? d_a.x : 0.0f, p1 ? d_a.y : 0.0f};
-            s_o = pk_fma(d_raw, G, s_o);
-            const f2 hh = d_raw * a;                       // = -2 dL/d(exponent); a == raw when it matters
-            // Sums are taken in the conic-weighted coordinates v: summing h*d and weighting by the
-            // conic afterwards would cancel large coherent sums for elongated Gaussians.
-            const f2 vx = pk_fma(splat(R_cbh(R)), dy, splat(cadx));
-            const f2 vy = pk_fma(splat(R_cd(R)), dy, splat(cbdx));
-            const f2 hvx = hh * vx, hvy = hh * vy;
-            s_vx += hvx;
-            s_vy += hvy;
-            s_xx = pk_fma(hvx, vx, s_xx);
-            s_xy = pk_fma(hvx, vy, s_xy);
-            s_yy = pk_fma(hvy, vy, s_yy);
+        if (low0) {
+            half_low(0, R, k, red);
+            half_full(1, R, k, red, o, dx, adx2, bdx);
+        } else if (low1) {
+            half_full(0, R, k, red, o, dx, adx2, bdx);
+            half_low(1, R, k, red);
+        } else {
+            half_full(0, R, k, red, o, dx, adx2, bdx);
+            half_full(1, R, k, red, o, dx, adx2, bdx);
         }
         const bool any_geom = __ballot(any_pass) != 0ull;
         if (any_geom)
@@ -440,7 +475,10 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
 
 // ATOMIC = several waves share a tile (L > 16): their sums meet in pairgrad through float atomics
 // (pairgrad zeroed by the launcher).  Otherwise each record is written once with plain stores.
-template <bool ATOMIC>
+// The kernel is launched twice.  TINY = false handles the waves none of whose pixels ran below
+// kTinyT and returns at once in the others; TINY = true does the opposite.  The plain sweep then
+// does not pay (in registers, hence in waves per SIMD) for the rarely needed checked one.
+template <bool TINY, bool ATOMIC>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                             const float *__restrict__ stream_rec,
                                                             const float *__restrict__ final_T,
@@ -456,7 +494,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
     bool tiny = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int y = w.y0 + j;
+        const int y = w.y0 + 4 * j;   // j = 0, 1: top half of the block; 2, 3: bottom half
         const int h = j >> 1, e = j & 1;
         pyf[h][e] = (float)y;
         T[h][e] = 0.0f; gr[h][e] = gg[h][e] = gb[h][e] = 0.0f;   // a pixel outside the tile contributes exact zeros
@@ -468,7 +506,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
         }
     }
     uint32_t nstop[4] = {0u, 0u, 0u, 0u};
-    if (__ballot(tiny) != 0ull) {
+    if ((__ballot(tiny) != 0ull) != TINY) return;
+    if (TINY) {
         // Some pixel's transmittance ran below kTinyT (long or opaque lists; it may have underflowed
         // to zero, where dividing back is impossible).  Re-run the forward recurrence to find, per
         // pixel, the entry after which T < kTinyT and the T there; later entries are dropped for
@@ -481,7 +520,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
             Rec R;
             rec_request(stream_rec, k, R);
             rec_wait(R);
-            const bool low = rec_all_clamped_low(R);
+            const bool low[2] = {rec_low_top(R), rec_low_bottom(R)};
+            const float o = rec_opacity(R);
             const float dx = R_gx(R) - pxf;
             const float adx2 = R_A(R) * dx * dx;
             const float bdx = R_B(R) * dx;
@@ -489,7 +529,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
             for (int j = 0; j < 4; ++j) {
                 const float dy = R_gy(R) - pyf[j >> 1][j & 1];
                 const float q = fmaf(fmaf(R_D(R), dy, bdx), dy, adx2);
-                const float a = low ? kAlphaMin : clamp_alpha(R_o(R) * __builtin_amdgcn_exp2f(q));
+                const float a = low[j >> 1] ? kAlphaMin : clamp_alpha(o * __builtin_amdgcn_exp2f(q));
                 Tf[j] = Tf[j] * (1.0f - a);
                 const bool hit = (Tf[j] < kTinyT) && (nstop[j] == len);
                 nstop[j] = hit ? (k - w.begin + 1u) : nstop[j];
@@ -498,7 +538,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool inside = w.vx && (w.y0 + j) < w.ylim;
+            const bool inside = w.vx && (w.y0 + 4 * j) < w.ylim;
             if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
         bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pair_slot, pairgrad);
@@ -538,10 +578,14 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
     const dim3 grid(gsr_div_up(waves, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
     if (S > 1) {
         (void)hipMemsetAsync(pairgrad, 0, (size_t)num_pairs * GSR_PAIRGRAD_FLOATS * sizeof(float), (hipStream_t)stream);
-        hipLaunchKernelGGL(composite_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, v, tile_offsets,
+        hipLaunchKernelGGL((composite_bwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
+                           stream_rec, final_T, dimg, pair_slot, pairgrad);
+        hipLaunchKernelGGL((composite_bwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
                            stream_rec, final_T, dimg, pair_slot, pairgrad);
     } else {
-        hipLaunchKernelGGL(composite_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, v, tile_offsets,
+        hipLaunchKernelGGL((composite_bwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
+                           stream_rec, final_T, dimg, pair_slot, pairgrad);
+        hipLaunchKernelGGL((composite_bwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
                            stream_rec, final_T, dimg, pair_slot, pairgrad);
     }
     return gsr_check_launch("composite_bwd");

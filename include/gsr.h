@@ -133,8 +133,9 @@ int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uin
  * Outputs: tile_offsets[T+1] u32 (tile id = yi + n_block_h * xi, Utils/Screen.py:38-39),
  * pair_slot[I] (emission slot of the pair at each sorted position), sorted_gauss[I] (Gaussian
  * index at each sorted position - the concatenated per-tile depth-ordered lists), stream_rec[I,12]
- * (the splat records in that order; the sign bit of a record's opacity marks a pair whose alpha is
- * 0.01 on the whole tile).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
+ * (the splat records in that order; two sign bits carry hints for the compositing kernels: that of
+ * the opacity is set when alpha is 0.01 on every pixel of the top 8 rows of a 16x16 tile, that of
+ * the red colour for the bottom 8 rows; for other tile sizes both describe the whole tile).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
 size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs);
 int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_base, const int32_t *bbox,
                   const uint32_t *ntiles, const float *rec, uint32_t num_pairs,

@@ -16,7 +16,7 @@ nbh = (H + 15) // 16
 g = torch.Generator().manual_seed(0)
 tiles = torch.randint(0, off.numel() - 1, (200,), generator=g).tolist()
 tot = flagged = geom = nongeom = 0
-npass = []
+npass = []; half_tb = []; half_lr = []; bands = []
 runs = []
 for t in tiles:
     b, e = int(off[t]), int(off[t + 1])
@@ -34,6 +34,13 @@ for t in tiles:
     fl = r[:, 5] < 0
     tot += e - b; flagged += int(fl.sum()); geom += int((~fl & anyp).sum()); nongeom += int((~fl & ~anyp).sum())
     npass.append(ps[~fl & anyp].float().sum(1))
+    low = (raw < 0.01)[~fl]                      # [n, x, y]
+    if low.shape[1] == 16 and low.shape[2] == 16:
+        top, bot = low[:, :, :8].flatten(1).all(1), low[:, :, 8:].flatten(1).all(1)
+        lef, rig = low[:, :8, :].flatten(1).all(1), low[:, 8:, :].flatten(1).all(1)
+        half_tb.append((top.float() + bot.float())); half_lr.append((lef.float() + rig.float()))
+        q = [low[:, :, 4 * b:4 * b + 4].flatten(1).all(1).float() for b in range(4)]
+        bands.append(sum(q))
     f = fl.cpu().tolist(); k = 0
     while k < len(f):
         if f[k]:
@@ -47,3 +54,8 @@ print("geometric entries: passing pixels of 256: mean %.1f median %.0f; <=16 px:
     npass.mean(), npass.median(), (npass <= 16).float().mean(), (npass <= 64).float().mean()))
 runs = torch.tensor(runs).float()
 print("flagged runs: mean length %.2f, entries in runs >= 2: %.3f, >= 4: %.3f" % (runs.mean(), runs[runs >= 2].sum() / runs.sum(), runs[runs >= 4].sum() / runs.sum()))
+
+tb = torch.cat(half_tb); lr = torch.cat(half_lr); bd = torch.cat(bands)
+print("non-flagged entries: fully-clamped-low halves (top/bottom split): mean %.3f of 2 ; P(exactly one) %.3f" % (tb.mean(), (tb == 1).float().mean()))
+print("non-flagged entries: left/right split: mean %.3f of 2" % lr.mean())
+print("non-flagged entries: four 4-row bands clamped-low: mean %.3f of 4" % bd.mean())

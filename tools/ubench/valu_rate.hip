@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void k(float *out, float seed)
             if (KIND == 20) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) % UNROLL]));
             if (KIND == 21) asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(a[i]) : "v"(a[(i + 1) % UNROLL]));
             if (KIND == 22) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(a[i]));
+            if (KIND == 23) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
+            if (KIND == 24) asm volatile("v_cmp_lt_f32_e64 s[10:11], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(m) : "s10", "s11");
+            if (KIND == 25) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
             if (KIND == 18) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(m) : "s10", "s11");
         }
     }
@@ -97,6 +100,7 @@ int main()
     run<10>("v_fmac_f32_e32", out); run<13>("v_fmac_f32_e32 (sgpr)", out); run<17>("v_fma_f32 acc form", out);
     run<11>("v_add_f32_e32", out); run<14>("v_max_f32_e32", out); run<12>("v_cmp_lt_f32_e32", out);
     run<15>("v_mov_b32_e32", out); run<16>("v_pk_add_f32", out);
+    run<23>("cmp_e32+cndmask vcc (2)", out); run<24>("cmp_e64+cndmask sgpr (2)", out); run<25>("cmp_e32+add+cndmask vcc (3)", out);
     run<19>("v_permlane32_swap", out); run<20>("v_permlane16_swap", out);
     run<21>("v_add_dpp ror8 bank c", out); run<22>("v_add_dpp row_bcast15", out);
     clock_probe();
