@@ -16,21 +16,6 @@ __global__ void iota_kernel(uint32_t *__restrict__ out, uint32_t n)
     if (i < n) out[i] = i;
 }
 
-__global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
-                                  uint32_t *__restrict__ out, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = src[idx[i]];
-}
-
-__global__ void scatter_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
-                                   uint32_t *__restrict__ out, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[idx[i]] = src[i];
-}
-
-// One thread per Gaussian: write the tile id of each of its pairs into its slots.
 // Slot e of Gaussian g: e = slot_base[g] + (xi - x0) * ny + (yi - y0).
 __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t *__restrict__ slot_base,
                                                          const int32_t *__restrict__ bbox,
@@ -166,19 +151,22 @@ extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint
     if (!depth_key || !ntiles || !order || !slot_base) { gsr_set_error("gsr_bin_offsets: null pointer"); return GSR_ERR_ARG; }
     const size_t arr = align256((size_t)n * sizeof(uint32_t));
     char *ws = (char *)workspace;
-    uint32_t *ids = (uint32_t *)ws;               // 0..n-1, clobbered by the sort
-    uint32_t *keys_sorted = (uint32_t *)(ws + arr);
-    uint32_t *tmp = (uint32_t *)(ws + 2 * arr);   // ntiles in depth order, then their scan
+    uint32_t *ids_b = (uint32_t *)ws;             // second value buffer of the sort
+    uint32_t *keys_b = (uint32_t *)(ws + arr);    // second key buffer of the sort
     void *sort_ws = ws + 3 * arr;
     const size_t sort_bytes = gsr_sort_workspace_bytes(n);
     void *scan_ws = (char *)sort_ws + sort_bytes;
     const size_t scan_bytes = gsr_scan_workspace_bytes(n);
     const dim3 grid(gsr_div_up(n, 256)), block(256);
-    hipLaunchKernelGGL(iota_kernel, grid, block, 0, st, ids, n);
-    if (int e = gsr_sort_pairs(depth_key, ids, keys_sorted, order, n, 0, 32, sort_ws, sort_bytes, stream)) return e;
-    hipLaunchKernelGGL(gather_u32_kernel, grid, block, 0, st, ntiles, order, tmp, n);
-    if (int e = gsr_exclusive_scan(tmp, tmp, n, &counters->num_pairs, scan_ws, scan_bytes, stream)) return e;
-    hipLaunchKernelGGL(scatter_u32_kernel, grid, block, 0, st, tmp, order, slot_base, n);
+    // 32 key bits = an even number of passes: the sorted indices come back to the buffer they start in
+    hipLaunchKernelGGL(iota_kernel, grid, block, 0, st, order, n);
+    bool in_first;
+    if (int e = gsr_sort_pingpong32(depth_key, order, keys_b, ids_b, n, 0, 32, sort_ws, sort_bytes, stream, &in_first))
+        return e;
+    if (!in_first) { gsr_set_error("gsr_bin_offsets: unexpected number of sort passes"); return GSR_ERR_LAUNCH; }
+    // slot_base[order[s]] = sum over s' < s of ntiles[order[s']]
+    if (int e = gsr_exclusive_scan_along(ntiles, order, slot_base, n, &counters->num_pairs, scan_ws, scan_bytes, stream))
+        return e;
     return gsr_check_launch("bin_offsets");
 }
 
@@ -219,11 +207,12 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_bas
     const size_t sort_bytes = workspace_bytes - 6 * arr;
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, slot_base, bbox, ntiles,
                        tile_key, owner_slot, num_pairs);
-    if (int e = gsr_sort_pairs64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0,
-                                 bits_for((uint32_t)v.T), sort_ws, sort_bytes, stream))
+    bool in_first;
+    if (int e = gsr_sort_pingpong64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0,
+                                    bits_for((uint32_t)v.T), sort_ws, sort_bytes, stream, &in_first))
         return e;
-    hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v, sorted_tile,
-                       sorted_owner_slot, rec, num_pairs, (uint32_t)v.T, tile_offsets, pair_slot, sorted_gauss,
-                       stream_rec);
+    hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
+                       in_first ? tile_key : sorted_tile, in_first ? owner_slot : sorted_owner_slot, rec, num_pairs,
+                       (uint32_t)v.T, tile_offsets, pair_slot, sorted_gauss, stream_rec);
     return gsr_check_launch("bin_lists");
 }

@@ -21,6 +21,15 @@ void gsr_set_error(const char *fmt, ...);
 int gsr_make_view(const gsr_view *v, ViewK *out);  // validates, returns GSR_OK / GSR_ERR_ARG
 int gsr_check_launch(const char *what);
 
+// scan_sort.hip, used by binning.hip: radix sort that ping-pongs between two buffer pairs without a
+// final copy (*result_in_first: sorted data is in the *_a buffers), and a scan along a permutation.
+int gsr_sort_pingpong32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, int begin_bit,
+                        int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
+int gsr_sort_pingpong64(uint32_t *keys_a, uint64_t *vals_a, uint32_t *keys_b, uint64_t *vals_b, uint32_t n, int begin_bit,
+                        int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
+int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 static inline unsigned gsr_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // Tiles lo/L .. (hi-1)/L overlap the integer interval [lo, hi) when hi > lo, none otherwise.

@@ -47,7 +47,10 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t x, uint32_t *lds, uint3
     return base + inc - x;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t n,
+// With idx != null element i of the sequence is in[idx[i]] and its result goes to out[idx[i]]
+// (a scan along a permutation; in and out may then not alias).
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t *__restrict__ in,
+                                                                   const uint32_t *__restrict__ idx, uint32_t n,
                                                                    uint32_t *__restrict__ block_sums)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) s += in[base + k];
+        if (base + k < n) s += in[idx ? idx[base + k] : base + k];
     uint32_t total;
     block_exclusive_scan(s, lds, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -78,24 +81,25 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ 
     if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t *__restrict__ in,
-                                                                  uint32_t *__restrict__ out, uint32_t n,
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t *in, const uint32_t *__restrict__ idx,
+                                                                  uint32_t *out, uint32_t n,
                                                                   const uint32_t *__restrict__ block_sums)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
+    uint32_t v[SCAN_ITEMS], at[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = base + k < n ? in[base + k] : 0u;
+        at[k] = base + k < n ? (idx ? idx[base + k] : base + k) : 0u;
+        v[k] = base + k < n ? in[at[k]] : 0u;
         s += v[k];
     }
     uint32_t total;
     uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan(s, lds, total);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) out[base + k] = run;
+        if (base + k < n) out[at[k]] = run;
         run += v[k];
     }
 }
@@ -120,6 +124,26 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
+// Turns the per-block digit counts into per-block offsets inside each digit: block d of this kernel
+// scans row d of hist (the nb counts of digit d, one per sort block) in place and writes the row total
+// to digit_total[d].  The scatter kernel adds the digit's own base (a scan of the 256 totals).
+__global__ __launch_bounds__(256) void radix_rows_kernel(uint32_t *__restrict__ hist, uint32_t nb,
+                                                         uint32_t *__restrict__ digit_total)
+{
+    __shared__ uint32_t lds[256 / 64 + 1];
+    uint32_t *row = hist + (size_t)blockIdx.x * nb;
+    uint32_t carry = 0;
+    for (uint32_t start = 0; start < nb; start += 256) {
+        const uint32_t i = start + threadIdx.x;
+        const uint32_t x = i < nb ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(x, lds, total);
+        if (i < nb) row[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
+
 // Stable scatter of one tile.  Wave w owns keys [w*1024, (w+1)*1024) of the tile, item `it` of a
 // wave is the 64 consecutive keys at it*64, so key order = (wave, item, lane).  Ranks inside a
 // wave come from ballots (lanes with an equal digit), per-wave digit counters live in LDS.
@@ -127,10 +151,17 @@ template <typename V>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     V *__restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nb,
-    const uint32_t *__restrict__ hist_scanned)
+    const uint32_t *__restrict__ hist_rows, const uint32_t *__restrict__ digit_total)
 {
     __shared__ uint32_t cnt[SORT_WAVES][RADIX_SIZE];
+    __shared__ uint32_t scan_lds[SORT_THREADS / 64 + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // first position of digit d in the output: exclusive scan of the 256 digit totals
+    uint32_t digit_base;
+    {
+        uint32_t all;
+        digit_base = block_exclusive_scan(digit_total[threadIdx.x], scan_lds, all);
+    }
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
     __syncthreads();
@@ -163,7 +194,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     {
         // thread d: global base of digit d for this block, then per-wave exclusive offsets
         const uint32_t d = threadIdx.x;
-        uint32_t run = hist_scanned[d * nb + blockIdx.x];
+        uint32_t run = digit_base + hist_rows[d * nb + blockIdx.x];
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) {
             const uint32_t c = cnt[w][d];
@@ -193,8 +224,9 @@ extern "C" size_t gsr_scan_workspace_bytes(uint32_t n)
     return align256((size_t)gsr_div_up(n ? n : 1, SCAN_TILE) * sizeof(uint32_t));
 }
 
-extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *workspace,
-                                  size_t workspace_bytes, void *stream)
+// library-internal: out[idx[i]] = sum over j < i of in[idx[j]]  (idx == null: the plain scan)
+int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
+                             void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (workspace_bytes < gsr_scan_workspace_bytes(n) || !workspace) {
@@ -209,24 +241,33 @@ extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n,
     if (!in || !out) { gsr_set_error("gsr_exclusive_scan: null pointer"); return GSR_ERR_ARG; }
     uint32_t *sums = (uint32_t *)workspace;
     const uint32_t nb = gsr_div_up(n, SCAN_TILE);
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb, total);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, out, n, sums);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, out, n, sums);
     return gsr_check_launch("exclusive_scan");
+}
+
+extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    return gsr_exclusive_scan_along(in, nullptr, out, n, total, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)
 {
     const uint32_t nb = gsr_div_up(n ? n : 1, SORT_TILE);
     const size_t hist = align256((size_t)nb * RADIX_SIZE * sizeof(uint32_t));
-    return hist + gsr_scan_workspace_bytes(nb * RADIX_SIZE);
+    return hist + align256(RADIX_SIZE * sizeof(uint32_t));
 }
 
+// Sorts between the two buffer pairs; *result_in_first tells where the sorted data ended up (the
+// *_a buffers after an even number of passes).  No copies.
 template <typename V>
-static int sort_pairs_impl(uint32_t *keys_in, V *vals_in, uint32_t *keys_out, V *vals_out, uint32_t n, int begin_bit,
-                           int end_bit, void *workspace, size_t workspace_bytes, void *stream)
+static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_b, uint32_t n, int begin_bit, int end_bit,
+                         void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first)
 {
     hipStream_t st = (hipStream_t)stream;
+    *result_in_first = true;
     if (begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) {
         gsr_set_error("gsr_sort_pairs: bad bit range [%d,%d)", begin_bit, end_bit);
         return GSR_ERR_ARG;
@@ -236,29 +277,52 @@ static int sort_pairs_impl(uint32_t *keys_in, V *vals_in, uint32_t *keys_out, V 
         return GSR_ERR_ARG;
     }
     if (n == 0) return GSR_OK;
-    if (!keys_in || !vals_in || !keys_out || !vals_out) { gsr_set_error("gsr_sort_pairs: null pointer"); return GSR_ERR_ARG; }
+    if (!keys_a || !vals_a || !keys_b || !vals_b) { gsr_set_error("gsr_sort_pairs: null pointer"); return GSR_ERR_ARG; }
     const uint32_t nb = gsr_div_up(n, SORT_TILE);
     uint32_t *hist = (uint32_t *)workspace;
     const size_t hist_bytes = align256((size_t)nb * RADIX_SIZE * sizeof(uint32_t));
-    void *scan_ws = (char *)workspace + hist_bytes;
-    const size_t scan_ws_bytes = workspace_bytes - hist_bytes;
-    uint32_t *ki = keys_in, *ko = keys_out;
-    V *vi = vals_in, *vo = vals_out;
-    bool in_out = false;  // where the current data is: false = the *_in buffers
+    uint32_t *digit_total = (uint32_t *)((char *)workspace + hist_bytes);
+    uint32_t *ki = keys_a, *ko = keys_b;
+    V *vi = vals_a, *vo = vals_b;
     for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
         const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
-        if (int e = gsr_exclusive_scan(hist, hist, nb * RADIX_SIZE, nullptr, scan_ws, scan_ws_bytes, stream)) return e;
+        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE), dim3(256), 0, st, hist, nb, digit_total);
         hipLaunchKernelGGL(radix_scatter_kernel<V>, dim3(nb), dim3(SORT_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask,
-                           nb, hist);
+                           nb, hist, digit_total);
         uint32_t *t = ki; ki = ko; ko = t;
         V *tv = vi; vi = vo; vo = tv;
-        in_out = !in_out;
+        *result_in_first = !*result_in_first;
     }
-    if (!in_out) {  // even number of passes (or none): the result sits in the *_in buffers
-        (void)hipMemcpyAsync(keys_out, keys_in, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
-        (void)hipMemcpyAsync(vals_out, vals_in, (size_t)n * sizeof(V), hipMemcpyDeviceToDevice, st);
+    return gsr_check_launch("sort_pairs");
+}
+
+// library-internal entry points (binning.hip): sort without the final copy
+int gsr_sort_pingpong32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, int begin_bit,
+                        int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first)
+{
+    return sort_pingpong<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, workspace, workspace_bytes,
+                                   stream, result_in_first);
+}
+int gsr_sort_pingpong64(uint32_t *keys_a, uint64_t *vals_a, uint32_t *keys_b, uint64_t *vals_b, uint32_t n, int begin_bit,
+                        int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first)
+{
+    return sort_pingpong<uint64_t>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, workspace, workspace_bytes,
+                                   stream, result_in_first);
+}
+
+template <typename V>
+static int sort_pairs_impl(uint32_t *keys_in, V *vals_in, uint32_t *keys_out, V *vals_out, uint32_t n, int begin_bit,
+                           int end_bit, void *workspace, size_t workspace_bytes, void *stream)
+{
+    bool in_first;
+    if (int e = sort_pingpong<V>(keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit, workspace, workspace_bytes,
+                                 stream, &in_first))
+        return e;
+    if (n && in_first) {  // even number of passes (or none): the result sits in the *_in buffers
+        (void)hipMemcpyAsync(keys_out, keys_in, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        (void)hipMemcpyAsync(vals_out, vals_in, (size_t)n * sizeof(V), hipMemcpyDeviceToDevice, (hipStream_t)stream);
     }
     return gsr_check_launch("sort_pairs");
 }
