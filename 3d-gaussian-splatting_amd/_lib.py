@@ -14,10 +14,12 @@ LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(CSRC, "libgsr.so")
 
 REC_FLOATS = 12
 PAIRGRAD_FLOATS = 12
+MAX_VIEWS = 8
 
 # Every symbol include/gsr.h declares.
 SYMBOLS = (
     "gsr_last_error", "gsr_version", "gsr_preprocess_fwd", "gsr_preprocess_bwd", "gsr_preprocess_bwd_workspace_bytes",
+    "gsr_pair_reduce", "gsr_preprocess_bwd_views",
     "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_sort_pairs64", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
     "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_lists_workspace_bytes", "gsr_bin_lists",
     "gsr_composite_fwd", "gsr_composite_bwd",
@@ -76,6 +78,9 @@ def load():
     vp = C.c_void_p
     lib.gsr_preprocess_fwd.argtypes = [C.POINTER(GsrView)] + [vp] * 16
     lib.gsr_preprocess_bwd.argtypes = [C.POINTER(GsrView)] + [vp] * 15 + [C.c_int, vp, C.c_size_t, vp]
+    lib.gsr_pair_reduce.argtypes = [C.c_uint32, vp, vp, vp, vp, vp, vp]
+    lib.gsr_preprocess_bwd_views.argtypes = ([C.POINTER(GsrView), C.c_uint32] + [vp] * 5 + [C.POINTER(vp)] * 2 + [vp] * 5 +
+                                             [C.POINTER(vp), C.c_int, vp])
     lib.gsr_sort_pairs.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
     lib.gsr_sort_pairs64.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
     lib.gsr_exclusive_scan.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_size_t, vp]

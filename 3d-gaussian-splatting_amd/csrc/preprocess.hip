@@ -47,8 +47,9 @@ __device__ inline float dot4_fma(const float *v, const float *row)
     return acc;
 }
 
-// GaussianModel.py:50-56,99-108; Utils/Transform.py:55-63,95-98; Utils/Camera.py:81-87,101-103.
-__device__ inline void geometry(const ViewK &v, const float p[3], const float sr[3], const float qr[4], Geom &g)
+// View-independent part: activations, rotation, 3-D covariance
+// (GaussianModel.py:50-56,99-108; Utils/Transform.py:55-63,95-98).
+__device__ inline void geometry_model(const float sr[3], const float qr[4], Geom &g)
 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) g.s[k] = (float)exp((double)sr[k]);
@@ -77,12 +78,18 @@ __device__ inline void geometry(const ViewK &v, const float p[3], const float sr
             for (int k = 0; k < 3; ++k) acc = acc + g.RS[i][k] * g.RS[j][k];
             g.cov3[i][j] = acc;
         }
+}
+
+// View-dependent part: clip position, NDC, M = J W, 2-D covariance (Utils/Camera.py:81-87,101-103).
+// w2m and proj are the view's row-major 4x4 matrices.
+__device__ inline void geometry_view(const float *w2m, const float *proj, const float p[3], Geom &g)
+{
     const float ph[4] = {p[0], p[1], p[2], 1.0f};
     float m[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m[j] = dot4_fma(ph, &v.w2m[4 * j]);
+    for (int j = 0; j < 4; ++j) m[j] = dot4_fma(ph, &w2m[4 * j]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) g.c[j] = dot4_fma(m, &v.proj[4 * j]);
+    for (int j = 0; j < 4; ++j) g.c[j] = dot4_fma(m, &proj[4 * j]);
 #pragma unroll
     for (int j = 0; j < 3; ++j) g.ndc[j] = g.c[j] / g.c[3];
     // J is built from the WORLD position; J01 = J10 = 0.
@@ -94,9 +101,9 @@ __device__ inline void geometry(const ViewK &v, const float p[3], const float sr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float acc = J[i][0] * v.w2m[4 * j + 0];
-            acc = __fmaf_rn(J[i][1], v.w2m[4 * j + 1], acc);
-            acc = __fmaf_rn(J[i][2], v.w2m[4 * j + 2], acc);
+            float acc = J[i][0] * w2m[4 * j + 0];
+            acc = __fmaf_rn(J[i][1], w2m[4 * j + 1], acc);
+            acc = __fmaf_rn(J[i][2], w2m[4 * j + 2], acc);
             g.M[i][j] = acc;
         }
 #pragma unroll
@@ -112,9 +119,9 @@ __device__ inline void geometry(const ViewK &v, const float p[3], const float sr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float acc = t2[i][0] * v.w2m[4 * 0 + j];
-            acc = __fmaf_rn(t2[i][1], v.w2m[4 * 1 + j], acc);
-            acc = __fmaf_rn(t2[i][2], v.w2m[4 * 2 + j], acc);
+            float acc = t2[i][0] * w2m[4 * 0 + j];
+            acc = __fmaf_rn(t2[i][1], w2m[4 * 1 + j], acc);
+            acc = __fmaf_rn(t2[i][2], w2m[4 * 2 + j], acc);
             t3[i][j] = acc;
         }
 #pragma unroll
@@ -126,6 +133,12 @@ __device__ inline void geometry(const ViewK &v, const float p[3], const float sr
             for (int k = 0; k < 3; ++k) acc = acc + t3[i][k] * J[j][k];
             g.cov2[2 * i + j] = acc;
         }
+}
+
+__device__ inline void geometry(const ViewK &v, const float p[3], const float sr[3], const float qr[4], Geom &g)
+{
+    geometry_model(sr, qr, g);
+    geometry_view(v.w2m, v.proj, p, g);
 }
 
 // SH basis of an un-normalised direction (Utils/SphericalHarmonic.py:62-88), degree <= 3.
@@ -372,84 +385,191 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, const uint8_t *
     }
 }
 
+// Launch constants of one view for the backward of stage 1.
+struct ViewCam {
+    float Wf, Hf;
+    float w2m[16];
+    float proj[16];
+    float cam[3];
+};
+constexpr int kMaxViews = GSR_MAX_VIEWS;
+struct BwdViews {
+    int nv;
+    ViewCam cam[kMaxViews];
+    const uint8_t *mask[kMaxViews];   // visibility of the view
+    const float *gsum[kMaxViews];     // summed gradient records of the view, [N,12]
+    float *g_screen[kMaxViews];       // gradient of the view's screen_coords leaf, [N,3]
+};
+
+// Backward of stage 1 for up to kMaxViews views of ONE parameter set: the gradients of all views are
+// summed in registers and the dense parameter gradients (236 bytes per Gaussian) are written once.
+// A view minibatch rendered one view at a time re-reads and re-writes them for every view.
+// Everything that does not depend on the view - the chain from the 3-D covariance back to the raw
+// scales and the quaternion - runs once on the summed dL/d(cov3).
 template <bool ACC>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
-    ViewK v, const float *__restrict__ coords, const float *__restrict__ scale_raw,
+    BwdViews a, int n, int deg, int K, const float *__restrict__ coords, const float *__restrict__ scale_raw,
     const float *__restrict__ rot_raw, const float *__restrict__ opac_raw, const float *__restrict__ sh,
-    const uint8_t *__restrict__ mask, const float *__restrict__ gsum, float *__restrict__ g_coords,
-    float *__restrict__ g_scale, float *__restrict__ g_rot, float *__restrict__ g_opac, float *__restrict__ g_sh,
-    float *__restrict__ g_screen)
+    float *__restrict__ g_coords, float *__restrict__ g_scale, float *__restrict__ g_rot, float *__restrict__ g_opac,
+    float *__restrict__ g_sh)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= v.n) return;
+    if (i >= n) return;
     float gc[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, gr[4] = {0.f, 0.f, 0.f, 0.f};
-    float gsc[2] = {0.f, 0.f}, go = 0.f;
+    float go = 0.f;
     float4 *dsh = reinterpret_cast<float4 *>(g_sh + (size_t)i * 48);
 
-    if (!mask[i]) {
+    bool any = false;
+    for (int vv = 0; vv < a.nv; ++vv) any |= a.mask[vv][i] != 0;
+    if (!any) {
+        for (int vv = 0; vv < a.nv; ++vv) {
+            float *gsv = a.g_screen[vv] + 3 * (size_t)i;
+            gsv[0] = 0.0f; gsv[1] = 0.0f; gsv[2] = 0.0f;
+        }
         if (!ACC) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) dsh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
-        // With h = -2 dL/d(exponent) per pixel, d = centre - pixel, C = inv(cov2) (symmetric part) and
-        // v = C d, the summed records hold: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2,
-        // dL/d(opacity), dL/d(colour).  exponent = d^T C d, so
-        //   dL/d(centre) = sum (-h/2) (2 v) = -sum h v,     dL/d(cov2) = sum (-h/2) (-v v^T) = 1/2 sum h v v^T.
-        const float4 *gsrc = reinterpret_cast<const float4 *>(gsum + (size_t)i * 12);
-        const float4 s0 = gsrc[0], s1 = gsrc[1], s2 = gsrc[2];
-        const double d_px = -(double)s0.x, d_py = -(double)s0.y;
-        const double D[2][2] = {{0.5 * (double)s0.z, 0.5 * (double)s0.w}, {0.5 * (double)s0.w, 0.5 * (double)s1.x}};
-        const double d_o = s1.y;
-        const float d_col[3] = {s1.z, s1.w, s2.x};
-
         const float p[3] = {coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
         const float sr[3] = {scale_raw[3 * i], scale_raw[3 * i + 1], scale_raw[3 * i + 2]};
         const float4 q4 = reinterpret_cast<const float4 *>(rot_raw)[i];
         const float qr[4] = {q4.x, q4.y, q4.z, q4.w};
+        Geom g;
+        geometry_model(sr, qr, g);
         double gp[3] = {0.0, 0.0, 0.0};
+        double dS[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};   // dL/d(cov3), summed over the views
+        double d_o = 0.0;
+
+        for (int vv = 0; vv < a.nv; ++vv) {
+            float gsc[2] = {0.f, 0.f};
+            if (a.mask[vv][i]) {
+                const ViewCam &cam = a.cam[vv];
+                // With h = -2 dL/d(exponent) per pixel, d = centre - pixel, C = inv(cov2) (symmetric part) and
+                // v = C d, the summed records hold: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y,
+                // sum h v_y^2, dL/d(opacity), dL/d(colour).  exponent = d^T C d, so
+                //   dL/d(centre) = sum (-h/2) (2 v) = -sum h v,   dL/d(cov2) = sum (-h/2) (-v v^T) = 1/2 sum h v v^T.
+                const float4 *gsrc = reinterpret_cast<const float4 *>(a.gsum[vv] + (size_t)i * 12);
+                const float4 s0 = gsrc[0], s1 = gsrc[1];
+                const double d_px = -(double)s0.x, d_py = -(double)s0.y;
+                const double D[2][2] = {{0.5 * (double)s0.z, 0.5 * (double)s0.w}, {0.5 * (double)s0.w, 0.5 * (double)s1.x}};
+                d_o += (double)s1.y;
+                geometry_view(cam.w2m, cam.proj, p, g);
+                // pixel centre -> NDC (+ screen_coords) -> clip -> world  (Utils/Camera.py:102-115)
+                {
+                    const double dn[3] = {d_px * 0.5 * (double)cam.Wf, d_py * -0.5 * (double)cam.Hf, 0.0};
+                    gsc[0] = (float)dn[0]; gsc[1] = (float)dn[1];
+                    const double c3 = (double)g.c[3];
+                    double dc[4];
+                    dc[3] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { dc[j] = dn[j] / c3; dc[3] -= dn[j] * (double)g.c[j] / (c3 * c3); }
+                    double dm[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        dm[k] = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dm[k] += dc[j] * (double)cam.proj[4 * j + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gp[k] += dm[j] * (double)cam.w2m[4 * j + k];
+                }
+                // cov2 = M S M^T with M = J W
+                double dM[2][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) t += (double)g.M[rr][r] * D[rr][c] * (double)g.M[c][b];
+                        dS[r][b] += t;
+                    }
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b)
+                                t += D[r][c] * (double)g.M[c][b] * (double)g.cov3[k][b] +
+                                     D[c][r] * (double)g.M[c][b] * (double)g.cov3[b][k];
+                        dM[r][k] = t;
+                    }
+                {
+                    // M = J W, W[k][j] = w2m[j][k]; J00 = J11 = 1/z, J02 = -x/z, J12 = -y/z (world x,y,z)
+                    double dJ[2][3];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            dJ[r][k] = 0.0;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) dJ[r][k] += dM[r][j] * (double)cam.w2m[4 * j + k];
+                        }
+                    const double x = p[0], y = p[1], z = p[2];
+                    gp[0] += dJ[0][2] * (-1.0 / z);
+                    gp[1] += dJ[1][2] * (-1.0 / z);
+                    gp[2] += (dJ[0][0] + dJ[1][1]) * (-1.0 / (z * z)) + dJ[0][2] * (x / (z * z)) + dJ[1][2] * (y / (z * z));
+                }
+            }
+            // screen_coords is a fresh leaf of every render (GaussianRenderer.py:64): its gradient belongs
+            // to its view alone and is never accumulated
+            float *gsv = a.g_screen[vv] + 3 * (size_t)i;
+            gsv[0] = gsc[0]; gsv[1] = gsc[1]; gsv[2] = 0.0f;
+        }
         // opacity = sigmoid(raw)
         const float o = 1.0f / (1.0f + expf(-opac_raw[i]));
         go = (float)(d_o * (double)(o * (1.0f - o)));
 
         // colour = max(sh . basis + 0.5, 0): gradient where the sum is >= 0 (torch.clamp rule).
-        // One channel at a time keeps the register footprint small.
+        // One channel at a time keeps the register footprint small; the basis depends on the view.
         {
-            float bs[16];
-            const float dx = p[0] - v.cam[0], dy = p[1] - v.cam[1], dz = p[2] - v.cam[2];
-            sh_basis(v.deg, dx, dy, dz, bs);
             const float4 *src = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                float co[16];
+                float co[16], acc[16];
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
                     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (v4 * 4 < v.K) t = src[ch * 4 + v4];
+                    if (v4 * 4 < K) t = src[ch * 4 + v4];
                     co[v4 * 4 + 0] = t.x; co[v4 * 4 + 1] = t.y; co[v4 * 4 + 2] = t.z; co[v4 * 4 + 3] = t.w;
                 }
-                float a = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < v.K) a += bs[k] * co[k];
-                a += 0.5f;
-                const float dc = (a >= 0.0f) ? d_col[ch] : 0.0f;
-                if (a >= 0.0f) {
-                    float dd[3];
-                    sh_dir_grad(v.deg, dx, dy, dz, co, dd);
-                    gp[0] += (double)dc * (double)dd[0];
-                    gp[1] += (double)dc * (double)dd[1];
-                    gp[2] += (double)dc * (double)dd[2];
+                for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+                for (int vv = 0; vv < a.nv; ++vv) {
+                    if (!a.mask[vv][i]) continue;
+                    const float d_col = a.gsum[vv][(size_t)i * 12 + 6 + ch];
+                    const float dx = p[0] - a.cam[vv].cam[0], dy = p[1] - a.cam[vv].cam[1], dz = p[2] - a.cam[vv].cam[2];
+                    float bs[16];
+                    sh_basis(deg, dx, dy, dz, bs);
+                    float t = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k < K) t += bs[k] * co[k];
+                    t += 0.5f;
+                    if (t >= 0.0f) {
+                        float dd[3];
+                        sh_dir_grad(deg, dx, dy, dz, co, dd);
+                        gp[0] += (double)d_col * (double)dd[0];
+                        gp[1] += (double)d_col * (double)dd[1];
+                        gp[2] += (double)d_col * (double)dd[2];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            if (k < K) acc[k] += d_col * bs[k];
+                    }
                 }
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
-                    float4 o4;
-                    o4.x = (4 * v4 + 0 < v.K) ? dc * bs[4 * v4 + 0] : 0.0f;
-                    o4.y = (4 * v4 + 1 < v.K) ? dc * bs[4 * v4 + 1] : 0.0f;
-                    o4.z = (4 * v4 + 2 < v.K) ? dc * bs[4 * v4 + 2] : 0.0f;
-                    o4.w = (4 * v4 + 3 < v.K) ? dc * bs[4 * v4 + 3] : 0.0f;
+                    float4 o4 = make_float4(acc[4 * v4], acc[4 * v4 + 1], acc[4 * v4 + 2], acc[4 * v4 + 3]);
                     if (ACC) {
-                        if (4 * v4 < v.K) {
+                        if (4 * v4 < K) {
                             const float4 t = dsh[ch * 4 + v4];
                             o4.x += t.x; o4.y += t.y; o4.z += t.z; o4.w += t.w;
                             dsh[ch * 4 + v4] = o4;
@@ -460,89 +580,24 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 }
             }
         }
-        Geom g;
-        geometry(v, p, sr, qr, g);
-        // pixel centre -> NDC (+ screen_coords) -> clip -> world  (Utils/Camera.py:102-115)
-        {
-            const double dn[3] = {d_px * 0.5 * (double)v.Wf, d_py * -0.5 * (double)v.Hf, 0.0};
-            gsc[0] = (float)dn[0]; gsc[1] = (float)dn[1];
-            const double c3 = (double)g.c[3];
-            double dc[4];
-            dc[3] = 0.0;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { dc[j] = dn[j] / c3; dc[3] -= dn[j] * (double)g.c[j] / (c3 * c3); }
-            double dm[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                dm[k] = 0.0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dm[k] += dc[j] * (double)v.proj[4 * j + k];
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) gp[k] += dm[j] * (double)v.w2m[4 * j + k];
-        }
-        // cov2 = M S M^T with M = J W
-        double dS[3][3], dM[2][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                double s = 0.0;
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) s += (double)g.M[r][a] * D[r][c] * (double)g.M[c][b];
-                dS[a][b] = s;
-            }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                double s = 0.0;
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        s += D[r][c] * (double)g.M[c][b] * (double)g.cov3[a][b] +
-                             D[c][r] * (double)g.M[c][b] * (double)g.cov3[b][a];
-                dM[r][a] = s;
-            }
-        {
-            // M = J W, W[k][j] = w2m[j][k]; J00 = J11 = 1/z, J02 = -x/z, J12 = -y/z (world x,y,z)
-            double dJ[2][3];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    dJ[r][k] = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) dJ[r][k] += dM[r][j] * (double)v.w2m[4 * j + k];
-                }
-            const double x = p[0], y = p[1], z = p[2];
-            gp[0] += dJ[0][2] * (-1.0 / z);
-            gp[1] += dJ[1][2] * (-1.0 / z);
-            gp[2] += (dJ[0][0] + dJ[1][1]) * (-1.0 / (z * z)) + dJ[0][2] * (x / (z * z)) + dJ[1][2] * (y / (z * z));
-        }
         {
             // cov3 = RS RS^T, RS = R diag(s), s = exp(raw), R = R(q), q = raw / max(|raw|, eps)
             double dRS[3][3], dR[3][3], ds[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    double s = 0.0;
+                    double t = 0.0;
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) s += (dS[a][b] + dS[b][a]) * (double)g.RS[b][k];
-                    dRS[a][k] = s;
+                    for (int b = 0; b < 3; ++b) t += (dS[r][b] + dS[b][r]) * (double)g.RS[b][k];
+                    dRS[r][k] = t;
                 }
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    dR[a][k] = dRS[a][k] * (double)g.s[k];
-                    ds[k] += dRS[a][k] * (double)g.R[a][k];
+                    dR[r][k] = dRS[r][k] * (double)g.s[k];
+                    ds[k] += dRS[r][k] * (double)g.R[r][k];
                 }
 #pragma unroll
             for (int k = 0; k < 3; ++k) gs[k] = (float)(ds[k] * (double)g.s[k]);
@@ -580,9 +635,6 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         *dst = o4;
     }
     put<ACC>(g_opac + i, go);
-    // screen_coords is a fresh leaf of every render (GaussianRenderer.py:64): its gradient belongs to
-    // this view alone and is never accumulated
-    g_screen[3 * i] = gsc[0]; g_screen[3 * i + 1] = gsc[1]; g_screen[3 * i + 2] = 0.0f;
 }
 
 }  // namespace
@@ -612,6 +664,68 @@ extern "C" size_t gsr_preprocess_bwd_workspace_bytes(uint32_t n)
     return ((size_t)(n ? n : 1) * 12 * sizeof(float) + 255) & ~(size_t)255;
 }
 
+extern "C" int gsr_pair_reduce(uint32_t n, const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
+                               const float *pairgrad, float *gsum, void *stream)
+{
+    if (n == 0) return GSR_OK;
+    if (!mask || !slot_base || !ntiles || !gsum) { gsr_set_error("gsr_pair_reduce: null pointer"); return GSR_ERR_ARG; }
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3(gsr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, (int)n, mask,
+                       slot_base, ntiles, pairgrad, gsum);
+    return gsr_check_launch("pair_reduce");
+}
+
+extern "C" int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num_views, const float *coords,
+                                        const float *scale_raw, const float *rot_raw, const float *opac_raw,
+                                        const float *sh, const uint8_t *const *mask_host, const float *const *gsum_host,
+                                        float *g_coords, float *g_scale, float *g_rot, float *g_opac, float *g_sh,
+                                        float *const *g_screen_host, int accumulate, void *stream)
+{
+    if (num_views == 0 || !views_host || !mask_host || !gsum_host || !g_screen_host) {
+        gsr_set_error("gsr_preprocess_bwd_views: no views or null view arrays");
+        return GSR_ERR_ARG;
+    }
+    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !g_coords || !g_scale || !g_rot || !g_opac || !g_sh) {
+        gsr_set_error("gsr_preprocess_bwd_views: null pointer");
+        return GSR_ERR_ARG;
+    }
+    ViewK first;
+    if (int e = gsr_make_view(&views_host[0], &first)) return e;
+    if (first.n == 0) return GSR_OK;
+    const dim3 grid(gsr_div_up(first.n, 256)), block(256);
+    // at most GSR_MAX_VIEWS views per launch; further groups add to the result of the first
+    for (uint32_t v0 = 0; v0 < num_views; v0 += kMaxViews) {
+        BwdViews a;
+        a.nv = (int)(num_views - v0 < (uint32_t)kMaxViews ? num_views - v0 : (uint32_t)kMaxViews);
+        for (int k = 0; k < a.nv; ++k) {
+            ViewK v;
+            if (int e = gsr_make_view(&views_host[v0 + k], &v)) return e;
+            if (v.n != first.n || v.deg != first.deg) {
+                gsr_set_error("gsr_preprocess_bwd_views: view %u differs from view 0 in n or sh_degree", v0 + k);
+                return GSR_ERR_ARG;
+            }
+            if (!mask_host[v0 + k] || !gsum_host[v0 + k] || !g_screen_host[v0 + k]) {
+                gsr_set_error("gsr_preprocess_bwd_views: null pointer for view %u", v0 + k);
+                return GSR_ERR_ARG;
+            }
+            ViewCam &c = a.cam[k];
+            c.Wf = v.Wf; c.Hf = v.Hf;
+            for (int j = 0; j < 16; ++j) { c.w2m[j] = v.w2m[j]; c.proj[j] = v.proj[j]; }
+            for (int j = 0; j < 3; ++j) c.cam[j] = v.cam[j];
+            a.mask[k] = mask_host[v0 + k];
+            a.gsum[k] = gsum_host[v0 + k];
+            a.g_screen[k] = g_screen_host[v0 + k];
+        }
+        for (int k = a.nv; k < kMaxViews; ++k) { a.mask[k] = nullptr; a.gsum[k] = nullptr; a.g_screen[k] = nullptr; }
+        if (accumulate || v0 > 0)
+            hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a, first.n, first.deg,
+                               first.K, coords, scale_raw, rot_raw, opac_raw, sh, g_coords, g_scale, g_rot, g_opac, g_sh);
+        else
+            hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a, first.n, first.deg,
+                               first.K, coords, scale_raw, rot_raw, opac_raw, sh, g_coords, g_scale, g_rot, g_opac, g_sh);
+    }
+    return gsr_check_launch("preprocess_bwd_views");
+}
+
 extern "C" int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
                                   const float *rot_raw, const float *opac_raw, const float *sh,
                                   const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
@@ -621,25 +735,15 @@ extern "C" int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords
 {
     ViewK v;
     if (int e = gsr_make_view(view_host, &v)) return e;
-    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !mask || !slot_base || !ntiles || !g_coords ||
-        !g_scale || !g_rot || !g_opac || !g_sh || !g_screen) {
-        gsr_set_error("gsr_preprocess_bwd: null pointer");
-        return GSR_ERR_ARG;
-    }
+    if (!mask || !slot_base || !ntiles || !g_screen) { gsr_set_error("gsr_preprocess_bwd: null pointer"); return GSR_ERR_ARG; }
     if (!workspace || workspace_bytes < gsr_preprocess_bwd_workspace_bytes((uint32_t)v.n)) {
         gsr_set_error("gsr_preprocess_bwd: workspace too small");
         return GSR_ERR_ARG;
     }
     if (v.n == 0) return GSR_OK;
     float *gsum = (float *)workspace;
-    const dim3 grid(gsr_div_up(v.n, 256)), block(256);
-    hipLaunchKernelGGL(pair_reduce_kernel, grid, block, 0, (hipStream_t)stream, v.n, mask, slot_base, ntiles, pairgrad,
-                       gsum);
-    if (accumulate)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, v, coords, scale_raw,
-                           rot_raw, opac_raw, sh, mask, gsum, g_coords, g_scale, g_rot, g_opac, g_sh, g_screen);
-    else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, v, coords, scale_raw,
-                           rot_raw, opac_raw, sh, mask, gsum, g_coords, g_scale, g_rot, g_opac, g_sh, g_screen);
-    return gsr_check_launch("preprocess_bwd");
+    if (int e = gsr_pair_reduce((uint32_t)v.n, mask, slot_base, ntiles, pairgrad, gsum, stream)) return e;
+    const float *gsum_c = gsum;
+    return gsr_preprocess_bwd_views(view_host, 1, coords, scale_raw, rot_raw, opac_raw, sh, &mask, &gsum_c, g_coords,
+                                    g_scale, g_rot, g_opac, g_sh, &g_screen, accumulate, stream);
 }

@@ -209,6 +209,56 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     return grads
 
 
+def backward_records(st: RenderState, dimg) -> torch.Tensor:
+    """First half of the backward of one view: compositing backward, then the per-Gaussian sums of
+    its gradient records.  Returns gsum [N,12]; pass it with the state to ``backward_views``."""
+    lib = _lib.load()
+    dev = st.mask_u8.device
+    stream = _stream(dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    dimg = dimg.to(torch.float32).contiguous()
+    I = st.num_pairs
+    pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
+    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.pair_slot),
+          _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
+    gsum = torch.empty(st.n, 12, **f32)
+    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad),
+          _ptr(gsum), stream)
+    return gsum
+
+
+def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grads=None, accumulate=False):
+    """Second half for a whole view minibatch: chains the per-Gaussian sums of all views to the raw
+    parameters and writes (or, with ``accumulate``, adds to) the five dense gradients ONCE.
+    ``states``/``gsums``: the views that had something visible.  Returns (grads, [g_screen per view])."""
+    import ctypes as C
+    lib = _lib.load()
+    dev = coords.device
+    n = coords.shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    if grads is None:
+        grads = (torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32),
+                 torch.empty(n, 1, **f32), torch.empty(n, 3, 16, **f32))
+    nv = len(states)
+    if nv == 0:
+        if not accumulate:
+            for g in grads:
+                g.zero_()
+        return grads, []
+    g_screens = [torch.empty(n, 3, **f32) for _ in range(nv)]
+    views = (_lib.GsrView * nv)(*[st.cview for st in states])
+    vp = C.c_void_p
+    masks = (vp * nv)(*[_ptr(st.mask_u8) for st in states])
+    sums = (vp * nv)(*[_ptr(g) for g in gsums])
+    screens = (vp * nv)(*[_ptr(g) for g in g_screens])
+    if opac_raw.dim() == 1:
+        opac_raw = opac_raw.unsqueeze(1)
+    _call("gsr_preprocess_bwd_views", lib.gsr_preprocess_bwd_views, views, nv, _ptr(coords.contiguous()),
+          _ptr(scale_raw.contiguous()), _ptr(rot_raw.contiguous()), _ptr(opac_raw.contiguous()), _ptr(sh.contiguous()),
+          masks, sums, *[_ptr(g) for g in grads], screens, 1 if accumulate else 0, _stream(dev))
+    return grads, g_screens
+
+
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view):

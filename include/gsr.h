@@ -96,6 +96,24 @@ int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const flo
                        float *g_opac, float *g_sh, float *g_screen, int accumulate, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* The two halves of gsr_preprocess_bwd, for view minibatches (the reference renders one view per
+ * optimiser step, Trainer.py:52-57; a minibatch sums the gradients of several renders of the same
+ * parameters).  gsr_pair_reduce sums one view's gradient records per Gaussian into gsum[N,12]
+ * (the nine sums of a record; floats 9..11 are 0).  gsr_preprocess_bwd_views then chains the sums of
+ * num_views views (host arrays of per-view device pointers) to the raw parameters in one pass: the
+ * dense gradients are written (accumulate == 0) or added to (accumulate != 0) ONCE for all views,
+ * where per-view calls of gsr_preprocess_bwd re-read and re-write them for every view.
+ * g_screen_host[v][N,3] receives view v's screen_coords gradient.  All views must share n and
+ * sh_degree.  At most GSR_MAX_VIEWS views go into one kernel launch; more are processed in groups. */
+#define GSR_MAX_VIEWS 8
+int gsr_pair_reduce(uint32_t n, const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
+                    const float *pairgrad, float *gsum, void *stream);
+int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num_views, const float *coords,
+                             const float *scale_raw, const float *rot_raw, const float *opac_raw,
+                             const float *sh, const uint8_t *const *mask_host, const float *const *gsum_host,
+                             float *g_coords, float *g_scale, float *g_rot, float *g_opac, float *g_sh,
+                             float *const *g_screen_host, int accumulate, void *stream);
+
 /* ---- stage 2: binning and sorting -----------------------------------------------------
  * Replaces Utils/Screen.py:38-62 (tile geometry + membership masks) and the per-tile argsort
  * with its gathers (GaussianRenderer.py:85-95).  The (tile, depth) radix sort is least-

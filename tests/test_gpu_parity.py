@@ -244,3 +244,60 @@ def test_opaque_stack_underflows_the_transmittance(oracle_mod, tile):
     ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 2, 96, 80, tile, a["w2m"],
                             a["proj"], a["cam_pos"], dimg=cot)
     compare(hip, ora)
+
+
+def test_view_minibatch_backward_equals_the_sum_of_single_views(oracle_mod):
+    """gsr_preprocess_bwd_views chains several views at once: its dense gradients equal the sum of the
+    per-view backward passes (and of the oracle's), its screen_coords gradients stay per view."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.camera import Camera
+    from gsplat_amd.rasterizer import ViewSpec, backward_pipeline, backward_records, backward_views, forward_pipeline
+    from gsplat_amd.scenes import synthetic_scene
+    dev = _gpu()
+    sc = synthetic_scene(6000, 192, 112, 3, 21)
+    p = [t.to(dev) for t in sc.params()]
+    nv = 10   # more than one launch group
+    cams, cots = [], []
+    gen = torch.Generator().manual_seed(3)
+    for v in range(nv):
+        ang = 2.0 * np.pi * v / nv
+        pos = np.array([0.3 * np.cos(ang), 0.3 * np.sin(ang), 0.1 * v])
+        cams.append(Camera(pos, np.array([1.0, 0.0, 0.0, 0.0]), sc.fx, sc.fy, sc.width / 2, sc.height / 2, sc.width,
+                           sc.height, device=dev))
+        cots.append(torch.rand(sc.width, sc.height, 3, generator=gen))
+    views = [ViewSpec.from_camera(c, 3, 16) for c in cams]
+    states = [forward_pipeline(*p, None, v) for v in views]
+    assert all(st.num_visible > 0 for st in states)
+    # per view, accumulated one after the other
+    seq = None
+    seq_screen = []
+    for st, cot in zip(states, cots):
+        if seq is None:
+            g = backward_pipeline(st, *p, cot.to(dev))
+            seq = tuple(t.clone() for t in g)
+        else:
+            g = backward_pipeline(st, *p, cot.to(dev), accumulate_into=seq)
+        seq_screen.append(g[5].clone())
+    # all views at once
+    gsums = [backward_records(st, cot.to(dev)) for st, cot in zip(states, cots)]
+    grads, screens = backward_views(states, gsums, *p)
+    torch.cuda.synchronize()
+    names = ("g_coords", "g_scale", "g_rotation", "g_opacity", "g_sh")
+    for k, a, b in zip(names, grads, seq[:5]):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), k)
+    for v in range(nv):
+        assert_bit_equal(screens[v].cpu().numpy(), seq_screen[v].cpu().numpy(), f"g_screen[{v}]")
+    # and against the oracle, view by view
+    total = None
+    for cam, cot in zip(cams, cots):
+        o = oracle_mod.render(sc.coords.numpy(), sc.scale.numpy(), sc.rotation.numpy(), sc.opacity.numpy(), sc.sh.numpy(), 3,
+                              sc.width, sc.height, 16, cam.w2m_host, cam.proj_host,
+                              np.asarray(cam.transform.position, np.float32), dimg=cot.numpy())
+        part = [o[k].astype(np.float64) for k in names]
+        total = part if total is None else [a + b for a, b in zip(total, part)]
+    for k, a, b in zip(names, grads, total):
+        assert_close(a.cpu().numpy().reshape(b.shape), b.astype(np.float32), k, **GRAD_OUTLIERS)
+    # accumulate=True adds to what is there
+    again, _ = backward_views(states, gsums, *p, grads=tuple(t.clone() for t in grads), accumulate=True)
+    for k, a, b in zip(names, again, grads):
+        assert_close(a.cpu().numpy(), 2.0 * b.cpu().numpy(), k)
