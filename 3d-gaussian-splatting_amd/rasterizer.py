@@ -44,11 +44,14 @@ class StageTimer:
     """Optional per-stage device timing: HIP events recorded on the stream the kernels run on.
 
     ``with StageTimer() as t: ...render...`` then ``t.summary()`` -> {stage: (calls, total_ms)}.
+    ``only``: names of the entry points to time (default: all); an event pair costs a few
+    microseconds of device time, which adds up over a hundred calls per step.
     """
     active = None
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = []
+        self.only = None if only is None else set(only)
 
     def __enter__(self):
         StageTimer.active = self
@@ -69,7 +72,7 @@ class StageTimer:
 def _call(name, fn, *args):
     """Invoke one C-ABI entry point; raise on a non-zero code; time it when a StageTimer is active."""
     timer = StageTimer.active
-    if timer is None:
+    if timer is None or (timer.only is not None and name not in timer.only):
         _lib.check(fn(*args), name)
         return
     a = torch.cuda.Event(enable_timing=True)
@@ -102,16 +105,30 @@ class RenderState:
     """Everything one forward leaves behind for inspection and for the backward."""
     __slots__ = ("view", "cview", "n", "num_visible", "num_pairs", "mask_u8", "pos2d", "cov2d", "radius_full",
                  "bbox", "ntiles", "rec", "order", "slot_base", "tile_offsets", "pair_slot", "sorted_gauss",
-                 "stream_rec", "final_T", "img", "pairgrad")
+                 "stream_rec", "final_T", "img", "pairgrad", "_counters", "_host", "_ready")
 
     def __init__(self):
         for s in self.__slots__:
             setattr(self, s, None)
 
 
-def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec) -> RenderState:
-    """Stage 1 -> binning/sort -> compositing.  One host sync (reads 3 counters) in the middle,
-    needed to size the per-pair buffers."""
+_copy_streams = {}
+_pinned_pool = []
+
+
+def _copy_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _copy_streams:
+        _copy_streams[key] = torch.cuda.Stream(device=dev)
+    return _copy_streams[key]
+
+
+def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec) -> RenderState:
+    """Stage 1 and the depth order of one view, plus an asynchronous read-back of the three counters
+    (visible Gaussians, pairs, error) on a side stream.  Nothing here waits for the GPU, so a caller
+    with several views can enqueue this part for all of them before it calls ``forward_finish`` on
+    the first: the counters of the later views are then long on the host when they are needed and the
+    GPU never idles on a round trip."""
     lib = _lib.load()
     dev = coords.device
     n = coords.shape[0]
@@ -150,8 +167,36 @@ def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, vi
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _call("gsr_bin_offsets", lib.gsr_bin_offsets, _ptr(depth_key), _ptr(st.ntiles), n, _ptr(st.order), _ptr(st.slot_base),
                                    _ptr(counters), _ptr(ws), ws_bytes, stream)
-    host = counters.cpu()          # the one synchronisation of the forward
+    # read the counters back on a side stream: the copy is ordered after bin_offsets only, not after
+    # whatever the caller enqueues on the main stream next
+    main = torch.cuda.current_stream(dev)
+    side = _copy_stream(dev)
+    done = torch.cuda.Event()
+    done.record(main)
+    st._counters = counters
+    st._host = _pinned_pool.pop() if _pinned_pool else torch.empty(8, dtype=torch.int32, pin_memory=True)
+    st._ready = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        side.wait_event(done)
+        st._host.copy_(counters, non_blocking=True)
+        st._ready.record(side)
+    return st
+
+
+def forward_finish(st: RenderState) -> RenderState:
+    """Waits for the view's counters (the one synchronisation of a render), sizes the per-pair
+    buffers, builds the per-tile lists and composites."""
+    lib = _lib.load()
+    view, cv, n = st.view, st.cview, st.n
+    dev = st.mask_u8.device
+    stream = _stream(dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    st._ready.synchronize()
+    host = st._host
     st.num_visible, st.num_pairs, err = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2])
+    _pinned_pool.append(host)
+    st._host = st._counters = st._ready = None
     if err & 1:
         raise SingularCovarianceError("singular 2-D covariance in a Gaussian that lands in a tile")
     if st.num_visible == 0:
@@ -172,6 +217,12 @@ def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, vi
     _call("gsr_composite_fwd", lib.gsr_composite_fwd, cv, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.img), _ptr(st.final_T),
           stream)
     return st
+
+
+def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec) -> RenderState:
+    """Stage 1 -> binning/sort -> compositing of one view.  One host synchronisation (three counters)
+    in the middle, needed to size the per-pair buffers."""
+    return forward_finish(forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view))
 
 
 def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh, dimg, accumulate_into=None,
