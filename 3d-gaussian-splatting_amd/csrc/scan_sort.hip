@@ -147,14 +147,23 @@ __global__ __launch_bounds__(256) void radix_rows_kernel(uint32_t *__restrict__ 
 // Stable scatter of one tile.  Wave w owns keys [w*1024, (w+1)*1024) of the tile, item `it` of a
 // wave is the 64 consecutive keys at it*64, so key order = (wave, item, lane).  Ranks inside a
 // wave come from ballots (lanes with an equal digit), per-wave digit counters live in LDS.
-template <typename V>
+// The tile is first put in digit order inside LDS and written out from there: consecutive threads
+// then write consecutive addresses of a digit's run instead of 64 scattered words per instruction.
+// (STAGED = false writes straight from registers: for digits that are spread evenly over the 256
+// values - the depth bits - a digit's run inside a tile is only ~16 items and the detour through LDS
+// does not pay.)
+template <typename V, bool STAGED>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     V *__restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nb,
     const uint32_t *__restrict__ hist_rows, const uint32_t *__restrict__ digit_total)
 {
-    __shared__ uint32_t cnt[SORT_WAVES][RADIX_SIZE];
+    __shared__ uint32_t cnt[SORT_WAVES][RADIX_SIZE];   // per-wave digit counts, then per-wave local offsets
+    __shared__ uint32_t lstart[RADIX_SIZE];            // first local position of a digit inside the tile
+    __shared__ uint32_t gbase[RADIX_SIZE];             // first global position of the tile's run of a digit
     __shared__ uint32_t scan_lds[SORT_THREADS / 64 + 1];
+    __shared__ V stage[STAGED ? SORT_TILE : 1];        // keys (as words), then values, in digit order
+    uint32_t *stage_keys = reinterpret_cast<uint32_t *>(stage);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // first position of digit d in the output: exclusive scan of the 256 digit totals
     uint32_t digit_base;
@@ -166,7 +175,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
     __syncthreads();
 
-    const uint32_t wbase = blockIdx.x * SORT_TILE + wave * (SORT_ITEMS * 64);
+    const uint32_t tile_base = blockIdx.x * SORT_TILE;
+    const uint32_t tile_count = min((uint32_t)SORT_TILE, n - tile_base);
+    const uint32_t wbase = tile_base + wave * (SORT_ITEMS * 64);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t key[SORT_ITEMS], rank[SORT_ITEMS];
     volatile uint32_t *mycnt = cnt[wave];
@@ -192,26 +203,71 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
     {
-        // thread d: global base of digit d for this block, then per-wave exclusive offsets
+        // thread d: the tile's count of digit d -> local start (scan over digits), per-wave offsets
         const uint32_t d = threadIdx.x;
-        uint32_t run = digit_base + hist_rows[d * nb + blockIdx.x];
+        uint32_t c[SORT_WAVES], sum = 0;
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) {
-            const uint32_t c = cnt[w][d];
-            cnt[w][d] = run;
-            run += c;
+        for (int w = 0; w < SORT_WAVES; ++w) { c[w] = cnt[w][d]; sum += c[w]; }
+        const uint32_t gb = digit_base + hist_rows[d * nb + blockIdx.x];
+        uint32_t run;
+        if (STAGED) {
+            uint32_t all;
+            run = block_exclusive_scan(sum, scan_lds, all);   // local positions
+            lstart[d] = run;
+            gbase[d] = gb;
+        } else {
+            run = gb;                                         // global positions right away
         }
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) { cnt[w][d] = run; run += c[w]; }
+    }
+    __syncthreads();
+    if (!STAGED) {
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t i = wbase + it * 64 + lane;
+            if (i < n) {
+                const uint32_t d = (key[it] >> shift) & mask;
+                const uint32_t pos = cnt[wave][d] + rank[it];
+                keys_out[pos] = key[it];
+                vals_out[pos] = vals_in[i];
+            }
+        }
+        return;
+    }
+    // keys into digit order
+    uint32_t lpos[SORT_ITEMS];
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = wbase + it * 64 + lane;
+        const uint32_t d = (key[it] >> shift) & mask;
+        lpos[it] = cnt[wave][d] + rank[it];
+        if (i < n) stage_keys[lpos[it]] = key[it];
+    }
+    __syncthreads();
+    uint32_t gpos[SORT_ITEMS];
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t l = it * SORT_THREADS + threadIdx.x;   // local position in digit order
+        if (l < tile_count) {
+            const uint32_t k = stage_keys[l];
+            const uint32_t d = (k >> shift) & mask;
+            gpos[it] = gbase[d] + (l - lstart[d]);
+            keys_out[gpos[it]] = k;
+        }
+    }
+    __syncthreads();
+    // values the same way
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const uint32_t i = wbase + it * 64 + lane;
+        if (i < n) stage[lpos[it]] = vals_in[i];
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
-        const uint32_t i = wbase + it * 64 + lane;
-        if (i < n) {
-            const uint32_t d = (key[it] >> shift) & mask;
-            const uint32_t pos = cnt[wave][d] + rank[it];
-            keys_out[pos] = key[it];
-            vals_out[pos] = vals_in[i];
-        }
+        const uint32_t l = it * SORT_THREADS + threadIdx.x;
+        if (l < tile_count) vals_out[gpos[it]] = stage[l];
     }
 }
 
@@ -289,8 +345,8 @@ static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
         hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE), dim3(256), 0, st, hist, nb, digit_total);
-        hipLaunchKernelGGL(radix_scatter_kernel<V>, dim3(nb), dim3(SORT_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask,
-                           nb, hist, digit_total);
+        hipLaunchKernelGGL((radix_scatter_kernel<V, (sizeof(V) > 4)>), dim3(nb), dim3(SORT_THREADS), 0, st, ki, vi, ko,
+                           vo, n, bit, mask, nb, hist, digit_total);
         uint32_t *t = ki; ki = ko; ko = t;
         V *tv = vi; vi = vo; vo = tv;
         *result_in_first = !*result_in_first;
