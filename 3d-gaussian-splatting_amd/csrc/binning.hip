@@ -16,30 +16,61 @@ __global__ void iota_kernel(uint32_t *__restrict__ out, uint32_t n)
     if (i < n) out[i] = i;
 }
 
-// Slot e of Gaussian g: e = slot_base[g] + (xi - x0) * ny + (yi - y0).
-__global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t *__restrict__ slot_base,
+// Emits (tile id, owner | slot) for every slot.  Slot e of Gaussian g: e = slot_base[g] + (xi - x0) * ny
+// + (yi - y0).  A wave takes 64 Gaussians that are consecutive in DEPTH order: their slots form one
+// contiguous range, which the wave writes 64 slots at a time - lane j owns slot start + 64 k + j and
+// finds the Gaussian it belongs to with a binary search over the 64 slot bases (held one per lane).
+// All global writes are fully coalesced; one thread per Gaussian writing its own slots is not.
+__global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t *__restrict__ order,
+                                                         const uint32_t *__restrict__ slot_base,
                                                          const int32_t *__restrict__ bbox,
                                                          const uint32_t *__restrict__ ntiles,
                                                          uint32_t *__restrict__ tile_key,
                                                          uint64_t *__restrict__ owner_slot, uint32_t num_pairs)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= v.n) return;
-    const uint32_t nt = ntiles[g];
-    if (nt == 0) return;
-    const int4 bb = reinterpret_cast<const int4 *>(bbox)[g];
-    int x0, x1, y0, y1;
-    gsr_tile_span(bb.x, bb.z, v.L, x0, x1);
-    gsr_tile_span(bb.y, bb.w, v.L, y0, y1);
-    uint32_t e = slot_base[g];
-    for (int xi = x0; xi <= x1; ++xi)
-        for (int yi = y0; yi <= y1; ++yi) {
-            if (e < num_pairs) {  // guards a stale num_pairs; never taken on consistent input
-                tile_key[e] = (uint32_t)(yi + v.nbh * xi);
-                owner_slot[e] = ((uint64_t)(uint32_t)g << 32) | (uint64_t)e;   // carried through the tile sort
-            }
-            ++e;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;   // position in depth order
+    uint32_t g = 0, sb = 0xFFFFFFFFu, nt = 0;
+    int x0 = 0, y0 = 0, ny = 1;
+    if (s < v.n) {
+        g = order[s];
+        nt = ntiles[g];
+        sb = slot_base[g];
+        if (nt) {
+            const int4 bb = reinterpret_cast<const int4 *>(bbox)[g];
+            int x1, y1;
+            gsr_tile_span(bb.x, bb.z, v.L, x0, x1);
+            gsr_tile_span(bb.y, bb.w, v.L, y0, y1);
+            ny = y1 - y0 + 1;
         }
+    }
+    // the wave's slot range; lanes past the end of the model hold sb = 0xFFFFFFFF and nt = 0
+    const uint32_t start = __shfl(sb, 0, 64);
+    uint32_t end = sb == 0xFFFFFFFFu ? 0u : sb + nt;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) end = max(end, (uint32_t)__shfl_xor(end, d, 64));
+    end = min(end, num_pairs);   // guards a stale num_pairs; no effect on consistent input
+    const int lane = threadIdx.x & 63;
+    // (the trip count is wave-uniform: the shuffles below must see every lane)
+    for (uint32_t base = start; base < end; base += 64) {
+        const uint32_t pos = base + lane;
+        // owner = last lane whose first slot is <= pos (slot bases do not decrease along the wave;
+        // a Gaussian without tiles shares its base with its successor and is never the last one)
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi + 1) >> 1;
+            const uint32_t b = __shfl(sb, mid, 64);
+            if (b <= pos) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t og = __shfl(g, lo, 64), osb = __shfl(sb, lo, 64);
+        const int ox0 = __shfl(x0, lo, 64), oy0 = __shfl(y0, lo, 64), ony = __shfl(ny, lo, 64);
+        if (pos < end) {
+            const uint32_t local = pos - osb;
+            const uint32_t cx = local / (uint32_t)ony, cy = local - cx * (uint32_t)ony;
+            tile_key[pos] = (uint32_t)(oy0 + (int)cy + v.nbh * (ox0 + (int)cx));
+            owner_slot[pos] = ((uint64_t)og << 32) | (uint64_t)pos;   // carried through the tile sort
+        }
+    }
 }
 
 // True when alpha = clamp(opacity*G, 0.01, 0.99) is pinned at 0.01 on EVERY pixel of the tile
@@ -176,8 +207,8 @@ extern "C" size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs)
     return 6 * arr + gsr_sort_workspace_bytes(num_pairs);   // 2 key arrays + 2 arrays of 64-bit payloads
 }
 
-extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_base, const int32_t *bbox,
-                             const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
+extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, const uint32_t *slot_base,
+                             const int32_t *bbox, const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
                              uint32_t *tile_offsets, uint32_t *pair_slot, uint32_t *sorted_gauss,
                              float *stream_rec, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -193,7 +224,7 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_bas
         gsr_set_error("gsr_bin_lists: workspace too small");
         return GSR_ERR_ARG;
     }
-    if (!slot_base || !bbox || !ntiles || !rec || !pair_slot || !sorted_gauss || !stream_rec) {
+    if (!order || !slot_base || !bbox || !ntiles || !rec || !pair_slot || !sorted_gauss || !stream_rec) {
         gsr_set_error("gsr_bin_lists: null pointer");
         return GSR_ERR_ARG;
     }
@@ -205,8 +236,8 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_bas
     uint64_t *sorted_owner_slot = (uint64_t *)(ws + 4 * arr);
     void *sort_ws = ws + 6 * arr;
     const size_t sort_bytes = workspace_bytes - 6 * arr;
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, slot_base, bbox, ntiles,
-                       tile_key, owner_slot, num_pairs);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, order, slot_base, bbox,
+                       ntiles, tile_key, owner_slot, num_pairs);
     bool in_first;
     if (int e = gsr_sort_pingpong64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0,
                                     bits_for((uint32_t)v.T), sort_ws, sort_bytes, stream, &in_first))

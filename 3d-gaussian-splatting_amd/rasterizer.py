@@ -209,7 +209,7 @@ def forward_finish(st: RenderState) -> RenderState:
     st.stream_rec = torch.empty(max(I, 1), _lib.REC_FLOATS, **f32)
     ws_bytes = int(lib.gsr_bin_lists_workspace_bytes(I))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _call("gsr_bin_lists", lib.gsr_bin_lists, cv, _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
+    _call("gsr_bin_lists", lib.gsr_bin_lists, cv, _ptr(st.order), _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
                                  _ptr(st.tile_offsets), _ptr(st.pair_slot), _ptr(st.sorted_gauss),
                                  _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream)
     st.img = torch.empty(view.width, view.height, 3, **f32)

@@ -147,7 +147,8 @@ int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uin
                     uint32_t *slot_base, gsr_counters *counters, void *workspace,
                     size_t workspace_bytes, void *stream);
 
-/* Per-tile lists.  num_pairs must be the value read back from counters->num_pairs.
+/* Per-tile lists.  order and slot_base come from gsr_bin_offsets; num_pairs must be the value read
+ * back from counters->num_pairs.
  * Outputs: tile_offsets[T+1] u32 (tile id = yi + n_block_h * xi, Utils/Screen.py:38-39),
  * pair_slot[I] (emission slot of the pair at each sorted position), sorted_gauss[I] (Gaussian
  * index at each sorted position - the concatenated per-tile depth-ordered lists), stream_rec[I,12]
@@ -155,8 +156,8 @@ int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uin
  * the opacity is set when alpha is 0.01 on every pixel of the top 8 rows of a 16x16 tile, that of
  * the red colour for the bottom 8 rows; for other tile sizes both describe the whole tile).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
 size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs);
-int gsr_bin_lists(const gsr_view *view_host, const uint32_t *slot_base, const int32_t *bbox,
-                  const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
+int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, const uint32_t *slot_base,
+                  const int32_t *bbox, const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
                   uint32_t *tile_offsets, uint32_t *pair_slot, uint32_t *sorted_gauss,
                   float *stream_rec, void *workspace, size_t workspace_bytes, void *stream);
 
