@@ -13,6 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(CSRC, "libgsr.so")
 
 REC_FLOATS = 12
+STREAM_DWORDS = 16
 PAIRGRAD_FLOATS = 12
 MAX_VIEWS = 8
 
@@ -87,7 +88,7 @@ def load():
     lib.gsr_bin_offsets.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_bin_lists.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_composite_fwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp]
-    lib.gsr_composite_bwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, C.c_uint32, vp, vp]
+    lib.gsr_composite_bwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, C.c_uint32, vp, vp]
     _lib = lib
     return lib
 

@@ -106,25 +106,34 @@ __device__ inline bool tile_all_clamped_low(float gx, float gy, float A, float B
     return __log2f(o) - fmin + 4.0e-6f * mag + 1.0e-4f < -6.6438561898f;
 }
 
-// One thread per sorted position p: copy the owner's splat record into the stream, note the
-// owner and its emission slot, mark tile boundaries, and flag the halves of the tile's block on
-// which alpha is 0.01 everywhere (sign bit of the opacity: top 8 rows, sign bit of the red
-// colour: bottom 8 rows) so the compositing kernels can skip their exponentials there.
+// One thread per sorted position p: write the owner's splat record in stream layout (with the
+// pair's emission slot and the hint flags: the halves of the tile's block on which alpha is 0.01
+// everywhere, where the compositing kernels can skip their exponentials), note the owner, mark tile
+// boundaries.
 __global__ __launch_bounds__(256) void finalize_lists_kernel(
     ViewK v, const uint32_t *__restrict__ sorted_tile, const uint64_t *__restrict__ sorted_owner_slot,
     const float *__restrict__ rec, uint32_t num_pairs, uint32_t T, uint32_t *__restrict__ tile_offsets,
     uint32_t *__restrict__ pair_slot, uint32_t *__restrict__ sorted_gauss, float *__restrict__ stream_rec)
 {
+    // The 64-byte records of a wave's 64 pairs are one contiguous 4 KiB piece of the stream: they go
+    // through LDS so that every store instruction writes 1 KiB of consecutive addresses.
+    __shared__ float4 tile[256 * 4];
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= num_pairs) return;
+    const int lane = threadIdx.x & 63;
+    float4 *wave_tile = tile + (threadIdx.x - lane) * 4;
+    const uint32_t wave_first = p - lane;
+    if (wave_first >= num_pairs) return;   // whole wave out of range
+    float4 out[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                     make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (p < num_pairs) {
     const uint64_t os = sorted_owner_slot[p];
     const uint32_t g = (uint32_t)(os >> 32);
-    pair_slot[p] = (uint32_t)os;
+    if (pair_slot) pair_slot[p] = (uint32_t)os;
     sorted_gauss[p] = g;
     const float4 *src = reinterpret_cast<const float4 *>(rec + (size_t)g * GSR_REC_FLOATS);
-    float4 *dst = reinterpret_cast<float4 *>(stream_rec + (size_t)p * GSR_REC_FLOATS);
-    float4 a = src[0], b = src[1], c = src[2];
+    const float4 a = src[0], b = src[1], c = src[2];   // x y A' B' | D' o r g | b ca cbh cd
     const uint32_t cur = sorted_tile[p];
+    uint32_t flags;
     {
         const int xi = (int)(cur / (uint32_t)v.nbh), yi = (int)(cur - (uint32_t)xi * v.nbh);
         const float x0 = (float)(xi * v.L), y0 = (float)(yi * v.L);
@@ -138,14 +147,29 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
         } else {
             low_top = low_bottom = tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, y1);
         }
-        if (low_top) b.y = -b.y;      // opacity >= 0 ...
-        if (low_bottom) b.z = -b.z;   // ... and red = max(. + 0.5, 0) >= 0, so both sign bits are free
+        flags = (low_top ? 1u : 0u) | (low_bottom ? 2u : 0u);
     }
-    dst[0] = a; dst[1] = b; dst[2] = c;
+    // stream layout: y x D' A' | o B' r ca | g slot b flags | cbh 0 cd 0
+    out[0] = make_float4(a.y, a.x, b.x, a.z);
+    out[1] = make_float4(b.y, a.w, b.z, c.y);
+    out[2] = make_float4(b.w, __uint_as_float((uint32_t)os), c.x, __uint_as_float(flags));
+    out[3] = make_float4(c.z, 0.0f, c.w, 0.0f);
     const uint32_t first = p == 0 ? 0u : sorted_tile[p - 1] + 1u;
     for (uint32_t t = first; t <= cur; ++t) tile_offsets[t] = p;  // tiles (prev, cur] start at p
     if (p + 1 == num_pairs)
         for (uint32_t t = cur + 1; t <= T; ++t) tile_offsets[t] = num_pairs;
+    }
+    // record of lane l = float4 4 l .. 4 l + 3 of the wave's piece
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wave_tile[lane * 4 + q] = out[q];
+    __builtin_amdgcn_wave_barrier();
+    float4 *dst = reinterpret_cast<float4 *>(stream_rec + (size_t)wave_first * GSR_STREAM_DWORDS);
+    const uint32_t wave_f4 = min(64u, num_pairs - wave_first) * 4u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t f = q * 64 + lane;
+        if (f < wave_f4) dst[f] = wave_tile[f];
+    }
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -220,11 +244,15 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, c
         (void)hipMemsetAsync(tile_offsets, 0, (size_t)(v.T + 1) * sizeof(uint32_t), st);
         return GSR_OK;
     }
+    if ((unsigned long long)num_pairs * GSR_STREAM_DWORDS * 4ull >= (1ull << 32)) {
+        gsr_set_error("gsr_bin_lists: %u pairs: the record stream would reach 4 GiB (32-bit stream offsets)", num_pairs);
+        return GSR_ERR_ARG;
+    }
     if (!workspace || workspace_bytes < gsr_bin_lists_workspace_bytes(num_pairs)) {
         gsr_set_error("gsr_bin_lists: workspace too small");
         return GSR_ERR_ARG;
     }
-    if (!order || !slot_base || !bbox || !ntiles || !rec || !pair_slot || !sorted_gauss || !stream_rec) {
+    if (!order || !slot_base || !bbox || !ntiles || !rec || !sorted_gauss || !stream_rec) {
         gsr_set_error("gsr_bin_lists: null pointer");
         return GSR_ERR_ARG;
     }

@@ -4,12 +4,15 @@
 // (lane -> column x = lane/4, rows y0, y0+4, y0+8, y0+12 with y0 = lane%4).  The lane's first two
 // pixels lie in the top 8 rows of the block and the other two in the bottom 8 rows; each pair is
 // processed with packed fp32 instructions, and a pair is the unit of the clamped-low fast path
-// (see rec_low_top / rec_low_bottom).  A reference tile of edge L is covered
+// (see the hint flags of a record below).  A reference tile of edge L is covered
 // by ceil(L/16)^2 such waves, all streaming the tile's list.  The list is a contiguous stream of
-// 48-byte splat records in depth order; the record address is wave-uniform, so records are
-// fetched with scalar loads into SGPRs and broadcast to the vector ALU for free - no LDS
-// staging, no barriers, waves are fully independent.  The loop is FP32-VALU / transcendental
-// bound (one v_exp_f32 per pixel-Gaussian pair), not HBM bound.
+// 64-byte splat records in depth order; the record address is wave-uniform, so a record is fetched
+// with ONE scalar load into 16 SGPRs and broadcast to the vector ALU for free - no LDS staging,
+// no barriers, waves are fully independent.  The loops are bound by the vector ALU and by the
+// scalar unit, which the four SIMDs of a CU share: every scalar instruction of the per-entry
+// bookkeeping (addresses, waits, flag tests, branches) costs about four cycles of a busy SIMD,
+// so the loops are written to need as few of them as possible - 32-bit running byte offsets, one
+// load per record, hint flags and the gradient slot inside the record.
 //
 // Semantics follow the reference exactly (GaussianRenderer.py:100-112, Utils/Probability.py):
 // integer pixel coordinates, alpha = clamp(opacity*G, 0.01, 0.99) for EVERY list entry, the
@@ -31,6 +34,7 @@ struct WaveGeom {
     bool vx;             // column inside the tile and the image
     int ylim;            // rows < ylim are inside
     uint32_t begin, end; // list range (wave-uniform)
+    uint32_t total;      // records in the whole stream
 };
 
 __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ tile_offsets, WaveGeom &w)
@@ -53,80 +57,61 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
     w.vx = w.x < xlim;
     w.begin = tile_offsets[tile];
     w.end = tile_offsets[tile + 1];
+    w.total = tile_offsets[v.T];
     return true;
 }
 
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// One 48-byte splat record held in 12 SGPRs.
+// One 64-byte stream record (layout: GSR_STREAM_DWORDS in gsr.h) held in 16 SGPRs.  Values that
+// serve as the scalar operand of packed instructions sit at even positions: an aligned SGPR pair
+// whose low half is broadcast (op_sel_hi = 0) needs no copy.
 struct Rec {
-    f32x8 a;   // gx, gy, A, B, D, o, r, g   centre, pre-scaled conic (exp2 domain), opacity, red, green
-    f32x4 b;   // b, ca, cbh, cd             blue, conic a, (b+c)/2, d as they are (backward only)
+    f32x16 d;
 };
-#define R_gx(R) ((R).a[0])
-#define R_gy(R) ((R).a[1])
-#define R_A(R) ((R).a[2])
-#define R_B(R) ((R).a[3])
-#define R_D(R) ((R).a[4])
-#define R_o(R) ((R).a[5])
-#define R_r(R) ((R).a[6])
-#define R_g(R) ((R).a[7])
-#define R_b(R) ((R).b[0])
-#define R_ca(R) ((R).b[1])
-#define R_cbh(R) ((R).b[2])
-#define R_cd(R) ((R).b[3])
+#define R_gy(R) ((R).d[0])
+#define R_gx(R) ((R).d[1])
+#define R_D(R) ((R).d[2])
+#define R_A(R) ((R).d[3])
+#define R_o(R) ((R).d[4])
+#define R_B(R) ((R).d[5])
+#define R_r(R) ((R).d[6])
+#define R_ca(R) ((R).d[7])
+#define R_g(R) ((R).d[8])
+#define R_slot(R) (__float_as_uint((R).d[9]))
+#define R_b(R) ((R).d[10])
+#define R_flags(R) (__float_as_uint((R).d[11]))
+#define R_cbh(R) ((R).d[12])
+#define R_cd(R) ((R).d[14])
 
-// Scalar loads of record k, issued now and waited for later (rec_wait), so that the latency of
-// one record's fetch (a few hundred cycles from L2) overlaps the arithmetic of the previous one.
-// hipcc would otherwise sink the load below its last use to reuse the registers.  The waits are
-// written by hand because the compiler does not count loads issued from inline asm.
-__device__ inline void rec_request(const float *__restrict__ stream_rec, uint32_t k, Rec &R)
+// Scalar load of the record at byte offset `off` of the stream, issued now and waited for later
+// (rec_wait), so that the latency of one record's fetch (a few hundred cycles from L2) overlaps the
+// arithmetic of the previous one.  hipcc would otherwise sink the load below its last use to reuse
+// the registers.  The waits are written by hand because the compiler does not count loads issued
+// from inline asm.
+__device__ inline void rec_request(const float *__restrict__ stream_rec, uint32_t off, Rec &R)
 {
-    const float *p = stream_rec + (size_t)k * GSR_REC_FLOATS;
-    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(R.a), "=&s"(R.b) : "s"(p) : "memory");
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(R.d) : "s"(stream_rec), "s"(off) : "memory");
 }
-__device__ inline void rec_wait(Rec &R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b)::"memory"); }
+__device__ inline void rec_wait(Rec &R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.d)::"memory"); }
 
-
-// The same plus the record's emission slot (where its gradient record goes), for the backward.
-__device__ inline void rec_request(const float *__restrict__ stream_rec, const uint32_t *__restrict__ pair_slot,
-                                   uint32_t k, Rec &R, uint32_t &slot)
+// Pulls the cache lines of records some entries further on into L2 with a vector load whose result
+// is never used (`lane_off` is 0 for even lanes and +64 or -64 for odd ones: a call touches two
+// neighbouring records, and one call per two entries touches every line of the stream).  The scalar record loads then
+// hit L2 instead of waiting for HBM; a wave has only one record in flight, so HBM latency would
+// otherwise bound the stream rate.  `sink` must stay live until the wave drains its vector loads
+// (l2_touch_drain).
+__device__ inline void l2_touch(const float *stream_rec, uint32_t off, uint32_t lane_off, float &sink)
 {
-    const float *p = stream_rec + (size_t)k * GSR_REC_FLOATS;
-    const uint32_t *q = pair_slot + k;
-    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dword %2, %4, 0x0"
-                 : "=&s"(R.a), "=&s"(R.b), "=&s"(slot)
-                 : "s"(p), "s"(q)
-                 : "memory");
-}
-__device__ inline void rec_wait(Rec &R, uint32_t &slot)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(slot)::"memory");
-}
-
-// Pulls the cache lines of a record some entries further on into L2 with a vector load whose
-// result is never used: lanes alternate between the record's first and last dword (byte offsets 0
-// and 44).  Issued once per two entries (96 bytes of stream), the touched addresses are at most 52
-// bytes apart, so every 64-byte line of the stream is touched and no address leaves a record.
-// The scalar record loads then hit L2 instead of waiting for HBM; a wave has only one record in
-// flight, so HBM latency would otherwise bound the stream rate.  `sink` must stay live until the
-// wave drains its vector loads (l2_touch_drain).
-__device__ inline void l2_touch(const float *p, uint32_t lane_off, float &sink)
-{
-    asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(lane_off), "s"(p) : "memory");
+    const uint32_t voff = lane_off + off;   // one VALU add; the base stays in SGPRs
+    asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(voff), "s"(stream_rec) : "memory");
 }
 __device__ inline void l2_touch_drain(float &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
 
-// The list builder marks, per record, the halves of the 16x16 block on which alpha is pinned at
-// 0.01 for every pixel: sign bit of the opacity = top 8 rows, sign bit of the red colour = bottom 8
-// rows (both values are >= 0 by construction; read them through rec_opacity / rec_red).  For tiles larger than one block both bits describe the whole
-// tile.  Wave-uniform: scalar compares and branches.
-__device__ inline bool rec_low_top(const Rec &R) { return __float_as_int(R_o(R)) < 0; }
-__device__ inline bool rec_low_bottom(const Rec &R) { return __float_as_int(R_r(R)) < 0; }
-__device__ inline float strip_sign(float x) { return __int_as_float(__float_as_int(x) & 0x7fffffff); }
-__device__ inline float rec_opacity(const Rec &R) { return strip_sign(R_o(R)); }
-__device__ inline float rec_red(const Rec &R) { return strip_sign(R_r(R)); }
+// Hint flags of a record: the halves of the 16x16 block on which alpha is pinned at 0.01 for every
+// pixel (bit 0: top 8 rows, bit 1: bottom 8 rows; for tiles larger than one block both bits
+// describe the whole tile).  Wave-uniform: scalar compares and branches.
+constexpr uint32_t kLowTop = 1u, kLowBottom = 2u, kLowBoth = 3u;
 
 __device__ inline float clamp_alpha(float raw) { return fminf(fmaxf(raw, kAlphaMin), kAlphaMax); }
 
@@ -173,40 +158,46 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         T[h] = T[h] * (splat(1.0f) - a);   // same rounding as the reference's cumprod of (1 - alpha)
     };
     auto blend = [&](const Rec &R) {
-        const bool low0 = rec_low_top(R), low1 = rec_low_bottom(R);
-        const float red = rec_red(R);
-        if (low0 && low1) {
+        const float red = R_r(R);
+        if (R_flags(R) == kLowBoth) {
             half_low(0, R, red);
             half_low(1, R, red);
             return;
         }
-        const float o = rec_opacity(R);
+        const float o = R_o(R);
         const float dx = R_gx(R) - pxf;
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
-        // (the forward pass is bound by the rate of the scalar record fetches, not by arithmetic:
-        // treating a single clamped-low half separately only adds branches here)
+        // (treating a single clamped-low half separately only adds scalar work here: the forward
+        // loop is bound by the scalar unit, not by its arithmetic)
         half_full(0, R, red, o, bdx, adx2);
         half_full(1, R, red, o, bdx, adx2);
     };
-    const uint32_t touch_off = (threadIdx.x & 1) * 44u;
+    // odd lanes touch the record before the one named (offset - 64, in wrapping 32-bit arithmetic)
+    const uint32_t touch_off = (threadIdx.x & 1) ? 0u - 64u : 0u;
     float sink = 0.0f;
     if (w.begin < w.end) {
-        // two record buffers, alternating: while one is blended the other is in flight
-        const uint32_t last = w.end - 1;
-        uint32_t k = w.begin;
+        // Two record buffers, alternating: while one is blended the other is in flight.  All stream
+        // positions are 32-bit byte offsets (64 bytes per record).
+        const uint32_t off_last = (w.end - 1) * 64u;
+        const uint32_t off_stream_last = (w.total - 1) * 64u;   // the touches may run into the next lists
+        uint32_t off = w.begin * 64u;
         Rec A, B;
-        rec_request(stream_rec, k, A);
+        rec_request(stream_rec, off, A);
         for (;;) {
             rec_wait(A);
-            rec_request(stream_rec, min(k + 1, last), B);
-            l2_touch(stream_rec + (size_t)min(k + kTouchAhead, last) * GSR_REC_FLOATS, touch_off, sink);
+            uint32_t next = min(off + 64u, off_last);
+            rec_request(stream_rec, next, B);
+            l2_touch(stream_rec, min(off + kTouchAhead * 64u, off_stream_last), touch_off, sink);
             blend(A);
-            if (++k >= w.end) break;
+            if (off == off_last) break;
+            off = next;
             rec_wait(B);
-            rec_request(stream_rec, min(k + 1, last), A);
+            next = min(off + 64u, off_last);
+            rec_request(stream_rec, next, A);
             blend(B);
-            if (++k >= w.end) break;
+            if (off == off_last) break;
+            off = next;
         }
         rec_wait(A);   // nothing may be in flight when the wave ends
         rec_wait(B);
@@ -269,39 +260,49 @@ __device__ inline float sum16(float x) { return dpp_add<DPP_MIRROR>(sum8(x)); }
 // the row's part of the blue sum, record float 8 + r.
 // Colour-only records: after merge_halves(red, green) and merge_rows(.., blue) the rows hold red,
 // blue (rows 0-1), green, blue (rows 2-3): floats 6, 8, 7, 9; the other eight floats are zeros.
+// The twelve writers of a record store with ONE instruction under a constant exec mask.
+constexpr unsigned long long kFullWriters = 0x0103010301030103ull;   // lanes 8 g and lanes 16 r + 1
+constexpr unsigned long long kColWriters = (0x7Full | (3ull << 10)) | (1ull << 24) | (1ull << 39) | (1ull << 57);
 struct RecordLanes {
-    bool full_writer, full_main;   // lane writes a float of a full record / it is one of the 8 merged sums
-    uint32_t full_slot;
-    bool col_writer, col_zero;
-    uint32_t col_slot;
+    uint32_t full_off, col_off;   // byte offset of the lane's float inside a record
+    bool full_main, col_zero;     // the lane holds one of the 8 merged sums / writes a zero
 };
 __device__ inline RecordLanes record_lanes(int lane)
 {
     RecordLanes L;
     L.full_main = (lane & 7) == 0;
-    L.full_writer = L.full_main || (lane & 15) == 1;
-    L.full_slot = L.full_main ? (uint32_t)(lane >> 3) : 8u + (uint32_t)(lane >> 4);
+    L.full_off = 4u * (L.full_main ? (uint32_t)(lane >> 3) : 8u + (uint32_t)(lane >> 4));
     L.col_zero = lane < 6 || lane == 10 || lane == 11;
-    L.col_writer = L.col_zero || lane == 6 || lane == 24 || lane == 39 || lane == 57;
-    L.col_slot = (uint32_t)(lane & 15);
+    L.col_off = 4u * (uint32_t)(lane & 15);
     return L;
 }
 
+// dst = pairgrad + byte offset `rec_off` of the record; the writers are the lanes of `writers`.
 template <bool ATOMIC>
-__device__ inline void put_record_float(float *dst, float val)
+__device__ inline void put_record(float *pairgrad, uint32_t rec_off, uint32_t lane_off, float val,
+                                  unsigned long long writers)
 {
+    const uint32_t voff = lane_off + rec_off;
     if (ATOMIC) {
-        if (val != 0.0f) atomicAdd(dst, val);   // several waves share the record; it was zeroed by the launcher
+        // several waves share the record; it was zeroed by the launcher
+        if (((writers >> (threadIdx.x & 63)) & 1ull) && val != 0.0f)
+            atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(pairgrad) + voff), val);
     } else {
-        *dst = val;
+        // every lane of the wave is active here: set the writers, store, restore
+        asm volatile("s_mov_b64 exec, %3\n\t"
+                     "global_store_dword %0, %1, %2\n\t"
+                     "s_mov_b64 exec, -1"
+                     :
+                     : "v"(voff), "v"(val), "s"(pairgrad), "s"(writers)
+                     : "memory");
     }
 }
 
 // Full record, floats: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2, dL/d(opacity),
 // dL/d(red), dL/d(green), then four partial sums of dL/d(blue).
 template <bool ATOMIC>
-__device__ inline void reduce_store_full(const RecordLanes &L, float *dst, float vx, float vy, float xx, float xy,
-                                         float yy, float o, float r, float g, float b)
+__device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, uint32_t rec_off, float vx, float vy,
+                                         float xx, float xy, float yy, float o, float r, float g, float b)
 {
     // pairing order chosen so that group g of 8 lanes ends up with record float g
     const float m0 = merge_halves(vx, yy), m1 = merge_halves(xx, r), m2 = merge_halves(vy, o), m3 = merge_halves(xy, g);
@@ -309,15 +310,16 @@ __device__ inline void reduce_store_full(const RecordLanes &L, float *dst, float
     const float n1 = merge_rows(m2, m3);   // rows: vy, xy, o,  g
     const float all8 = sum8(merge_half_rows(n0, n1));
     const float blue = sum16(b);
-    if (L.full_writer) put_record_float<ATOMIC>(dst + L.full_slot, L.full_main ? all8 : blue);
+    put_record<ATOMIC>(pairgrad, rec_off, L.full_off, L.full_main ? all8 : blue, kFullWriters);
 }
 
 // Colour-only record (the clamp blocks every other gradient of the entry).
 template <bool ATOMIC>
-__device__ inline void reduce_store_colour(const RecordLanes &L, float *dst, float r, float g, float b)
+__device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad, uint32_t rec_off, float r, float g,
+                                           float b)
 {
     const float rows = sum16(merge_rows(merge_halves(r, g), b));   // rows: red, blue(0-1), green, blue(2-3)
-    if (L.col_writer) put_record_float<ATOMIC>(dst + L.col_slot, L.col_zero ? 0.0f : rows);
+    put_record<ATOMIC>(pairgrad, rec_off, L.col_off, L.col_zero ? 0.0f : rows, kColWriters);
 }
 
 // Reverse sweep of one list for the 4 pixels of a lane.  CHECK: pixel j only takes part in
@@ -325,8 +327,7 @@ __device__ inline void reduce_store_colour(const RecordLanes &L, float *dst, flo
 template <bool CHECK, bool ATOMIC>
 __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ stream_rec, const float pxf,
                                  const f2 (&pyf)[2], f2 (&T)[2], const f2 (&gr)[2], const f2 (&gg)[2],
-                                 const f2 (&gb)[2], const uint32_t (&nstop)[4],
-                                 const uint32_t *__restrict__ pair_slot, float *__restrict__ pairgrad)
+                                 const f2 (&gb)[2], const uint32_t (&nstop)[4], float *__restrict__ pairgrad)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
     const f2 py_top = pyf[0];
@@ -412,28 +413,28 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         s_xy = pk_fma(hvx, vy, s_xy);
         s_yy = pk_fma(hvy, vy, s_yy);
     };
-    auto entry = [&](const Rec &R, uint32_t k, uint32_t slot) {
-        float *dst = pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS;   // a Gaussian's records are contiguous
-        const bool low0 = rec_low_top(R), low1 = rec_low_bottom(R);
+    auto entry = [&](const Rec &R, uint32_t k) {
+        const uint32_t rec_off = R_slot(R) * (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));   // a Gaussian's records are contiguous
+        const uint32_t flags = R_flags(R);
         const f2 z = splat(0.f);
         s_r = s_g = s_b = z;
-        const float red = rec_red(R);
-        if (low0 && low1) {
+        const float red = R_r(R);
+        if (flags == kLowBoth) {
             half_low(0, R, k, red);
             half_low(1, R, k, red);
-            reduce_store_colour<ATOMIC>(lanes, dst, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+            reduce_store_colour<ATOMIC>(lanes, pairgrad, rec_off, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
             return;
         }
         s_vx = s_vy = s_xx = s_xy = s_yy = s_o = z;
         any_pass = false;
-        const float o = rec_opacity(R);
+        const float o = R_o(R);
         const float dx = R_gx(R) - pxf;
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
-        if (low0) {
+        if (flags == kLowTop) {
             half_low(0, R, k, red);
             half_full(1, R, k, red, o, dx, adx2, bdx);
-        } else if (low1) {
+        } else if (flags == kLowBottom) {
             half_full(0, R, k, red, o, dx, adx2, bdx);
             half_low(1, R, k, red);
         } else {
@@ -442,34 +443,40 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         }
         const bool any_geom = __ballot(any_pass) != 0ull;
         if (any_geom)
-            reduce_store_full<ATOMIC>(lanes, dst, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
+            reduce_store_full<ATOMIC>(lanes, pairgrad, rec_off, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
                                       s_yy.x + s_yy.y, s_o.x + s_o.y, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
         else
-            reduce_store_colour<ATOMIC>(lanes, dst, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+            reduce_store_colour<ATOMIC>(lanes, pairgrad, rec_off, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
     };
-    // back to front, two record buffers alternating (see composite_fwd_kernel)
-    uint32_t k = w.end - 1;   // the caller guarantees a non-empty list
-    Rec A, B;
-    uint32_t sa, sb;
-    const uint32_t touch_off = (threadIdx.x & 1) * 44u;
+    // back to front, two record buffers alternating (see composite_fwd_kernel); k is only needed by
+    // the checked variant
+    const uint32_t off_first = w.begin * 64u;
+    uint32_t off = (w.end - 1) * 64u;   // the caller guarantees a non-empty list
+    uint32_t k = w.end - 1;
+    const uint32_t touch_off = (threadIdx.x & 1) * 64u;
     float sink = 0.0f;
-    rec_request(stream_rec, pair_slot, k, A, sa);
+    Rec A, B;
+    rec_request(stream_rec, off, A);
     for (;;) {
-        rec_wait(A, sa);
-        rec_request(stream_rec, pair_slot, k > w.begin ? k - 1 : k, B, sb);
-        l2_touch(stream_rec + (size_t)(k - w.begin > kTouchAhead ? k - kTouchAhead : w.begin) * GSR_REC_FLOATS,
-                 touch_off, sink);
-        entry(A, k, sa);
-        if (k == w.begin) break;
-        --k;
-        rec_wait(B, sb);
-        rec_request(stream_rec, pair_slot, k > w.begin ? k - 1 : k, A, sa);
-        entry(B, k, sb);
-        if (k == w.begin) break;
-        --k;
+        rec_wait(A);
+        uint32_t next = max(off, off_first + 64u) - 64u;
+        rec_request(stream_rec, next, B);
+        // the two lines below the one sixteen entries down (never below the start of the stream)
+        l2_touch(stream_rec, max(off, (kTouchAhead + 1) * 64u) - (kTouchAhead + 1) * 64u, touch_off, sink);
+        entry(A, k);
+        if (off == off_first) break;
+        off = next;
+        if (CHECK) --k;
+        rec_wait(B);
+        next = max(off, off_first + 64u) - 64u;
+        rec_request(stream_rec, next, A);
+        entry(B, k);
+        if (off == off_first) break;
+        off = next;
+        if (CHECK) --k;
     }
-    rec_wait(A, sa);
-    rec_wait(B, sb);
+    rec_wait(A);
+    rec_wait(B);
     l2_touch_drain(sink);
 }
 
@@ -483,7 +490,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
                                                             const float *__restrict__ stream_rec,
                                                             const float *__restrict__ final_T,
                                                             const float *__restrict__ dimg,
-                                                            const uint32_t *__restrict__ pair_slot,
                                                             float *__restrict__ pairgrad)
 {
     WaveGeom w;
@@ -518,10 +524,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
         for (int j = 0; j < 4; ++j) { Tf[j] = 1.0f; Ts[j] = 0.0f; nstop[j] = len; }
         for (uint32_t k = w.begin; k < w.end; ++k) {
             Rec R;
-            rec_request(stream_rec, k, R);
+            rec_request(stream_rec, k * 64u, R);
             rec_wait(R);
-            const bool low[2] = {rec_low_top(R), rec_low_bottom(R)};
-            const float o = rec_opacity(R);
+            const bool low[2] = {(R_flags(R) & kLowTop) != 0, (R_flags(R) & kLowBottom) != 0};
+            const float o = R_o(R);
             const float dx = R_gx(R) - pxf;
             const float adx2 = R_A(R) * dx * dx;
             const float bdx = R_B(R) * dx;
@@ -541,9 +547,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
             const bool inside = w.vx && (w.y0 + 4 * j) < w.ylim;
             if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
-        bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pair_slot, pairgrad);
+        bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad);
     } else {
-        bwd_sweep<false, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pair_slot, pairgrad);
+        bwd_sweep<false, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad);
     }
 }
 
@@ -563,13 +569,17 @@ extern "C" int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile
 }
 
 extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, const float *stream_rec,
-                                 const uint32_t *pair_slot, const float *final_T, const float *dimg,
-                                 uint32_t num_pairs, float *pairgrad, void *stream)
+                                 const float *final_T, const float *dimg, uint32_t num_pairs, float *pairgrad,
+                                 void *stream)
 {
     ViewK v;
     if (int e = gsr_make_view(view_host, &v)) return e;
     if (num_pairs == 0) return GSR_OK;
-    if (!tile_offsets || !stream_rec || !pair_slot || !final_T || !dimg || !pairgrad) {
+    if ((unsigned long long)num_pairs * 64ull >= (1ull << 32)) {
+        gsr_set_error("gsr_composite_bwd: %u pairs: the record stream would reach 4 GiB", num_pairs);
+        return GSR_ERR_ARG;
+    }
+    if (!tile_offsets || !stream_rec || !final_T || !dimg || !pairgrad) {
         gsr_set_error("gsr_composite_bwd: null pointer");
         return GSR_ERR_ARG;
     }
@@ -579,14 +589,14 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
     if (S > 1) {
         (void)hipMemsetAsync(pairgrad, 0, (size_t)num_pairs * GSR_PAIRGRAD_FLOATS * sizeof(float), (hipStream_t)stream);
         hipLaunchKernelGGL((composite_bwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pair_slot, pairgrad);
+                           stream_rec, final_T, dimg, pairgrad);
         hipLaunchKernelGGL((composite_bwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pair_slot, pairgrad);
+                           stream_rec, final_T, dimg, pairgrad);
     } else {
         hipLaunchKernelGGL((composite_bwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pair_slot, pairgrad);
+                           stream_rec, final_T, dimg, pairgrad);
         hipLaunchKernelGGL((composite_bwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pair_slot, pairgrad);
+                           stream_rec, final_T, dimg, pairgrad);
     }
     return gsr_check_launch("composite_bwd");
 }

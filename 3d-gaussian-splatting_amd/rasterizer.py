@@ -204,13 +204,12 @@ def forward_finish(st: RenderState) -> RenderState:
     T = ((view.width + view.tile_length - 1) // view.tile_length) * ((view.height + view.tile_length - 1) // view.tile_length)
     I = st.num_pairs
     st.tile_offsets = torch.empty(T + 1, **i32)
-    st.pair_slot = torch.empty(max(I, 1), **i32)
     st.sorted_gauss = torch.empty(max(I, 1), **i32)
-    st.stream_rec = torch.empty(max(I, 1), _lib.REC_FLOATS, **f32)
+    st.stream_rec = torch.empty(max(I, 1), _lib.STREAM_DWORDS, **f32)
     ws_bytes = int(lib.gsr_bin_lists_workspace_bytes(I))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _call("gsr_bin_lists", lib.gsr_bin_lists, cv, _ptr(st.order), _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
-                                 _ptr(st.tile_offsets), _ptr(st.pair_slot), _ptr(st.sorted_gauss),
+                                 _ptr(st.tile_offsets), None, _ptr(st.sorted_gauss),
                                  _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream)
     st.img = torch.empty(view.width, view.height, 3, **f32)
     st.final_T = torch.empty(view.width, view.height, **f32)
@@ -239,8 +238,7 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
     pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
-    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.pair_slot),
-          _ptr(st.final_T),
+    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.final_T),
                                      _ptr(dimg), I, _ptr(pairgrad), stream)
     st.pairgrad = pairgrad
     if accumulate_into is None:
@@ -270,8 +268,7 @@ def backward_records(st: RenderState, dimg) -> torch.Tensor:
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
     pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
-    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.pair_slot),
-          _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
+    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
     gsum = torch.empty(st.n, 12, **f32)
     _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad),
           _ptr(gsum), stream)

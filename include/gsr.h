@@ -56,6 +56,15 @@ typedef struct gsr_counters {
 /* x, y, A', B', D', opacity, r, g, b, a, (b+c)/2, d   (48 bytes).  [a b; c d] = inverse 2-D
  * covariance; A' = k a, B' = k (b+c), D' = k d with k = -log2(e)/2, so G = exp2(A'dx^2+B'dxdy+D'dy^2) */
 #define GSR_REC_FLOATS 12
+/* The same record in per-tile list order, as the compositing kernels stream it: 16 dwords (64 bytes,
+ * one cache line, fetched with one scalar load).  Values used as the scalar operand of packed
+ * instructions sit at even dwords (an aligned register pair needs no copy):
+ *   0 y   1 x   2 D'   3 A'   4 opacity   5 B'   6 r   7 a   8 g   9 slot (u32)   10 b
+ *   11 flags (u32)   12 (b+c)/2   13 0   14 d   15 0
+ * slot  = the pair's emission slot (row of pairgrad its gradient record goes to);
+ * flags = hints: bit 0 / bit 1 set when alpha is 0.01 on every pixel of the top / bottom 8 rows of
+ *         a 16x16 tile (for other tile sizes both bits describe the whole tile). */
+#define GSR_STREAM_DWORDS 16
 /* Per-(tile,Gaussian) gradient record produced by the compositing backward. */
 /* With h = -2 dL/d(exponent) per pixel, d = centre - pixel and v = inverse covariance * d:
  * sum h v_x, sum h v_y, sum h v_x v_x, sum h v_x v_y, sum h v_y v_y, dL/d(opacity), dL/d(r), dL/d(g),
@@ -150,11 +159,10 @@ int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uin
 /* Per-tile lists.  order and slot_base come from gsr_bin_offsets; num_pairs must be the value read
  * back from counters->num_pairs.
  * Outputs: tile_offsets[T+1] u32 (tile id = yi + n_block_h * xi, Utils/Screen.py:38-39),
- * pair_slot[I] (emission slot of the pair at each sorted position), sorted_gauss[I] (Gaussian
- * index at each sorted position - the concatenated per-tile depth-ordered lists), stream_rec[I,12]
- * (the splat records in that order; two sign bits carry hints for the compositing kernels: that of
- * the opacity is set when alpha is 0.01 on every pixel of the top 8 rows of a 16x16 tile, that of
- * the red colour for the bottom 8 rows; for other tile sizes both describe the whole tile).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
+ * pair_slot[I] (emission slot of the pair at each sorted position; may be NULL), sorted_gauss[I] (Gaussian
+ * index at each sorted position - the concatenated per-tile depth-ordered lists),
+ * stream_rec[I,GSR_STREAM_DWORDS] (the stream records in that order, layout above).
+ * num_pairs * 64 must stay below 2^32 (the kernels address the stream with 32-bit byte offsets).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
 size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs);
 int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, const uint32_t *slot_base,
                   const int32_t *bbox, const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
@@ -170,11 +178,11 @@ int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets,
                       const float *stream_rec, float *img, float *final_T, void *stream);
 
 /* Backward of the blend (autograd of the statements above).  dimg[W,H,3] is dL/dimg.
- * pairgrad[I,12] is fully overwritten; the record of the pair at sorted position p goes to row
- * pair_slot[p]. */
+ * pairgrad[I,12] is fully overwritten; the record of the pair at sorted position p goes to the row
+ * named by its stream record's slot field (= pair_slot[p]). */
 int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets,
-                      const float *stream_rec, const uint32_t *pair_slot, const float *final_T,
-                      const float *dimg, uint32_t num_pairs, float *pairgrad, void *stream);
+                      const float *stream_rec, const float *final_T, const float *dimg,
+                      uint32_t num_pairs, float *pairgrad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ __device__ inline f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma
 __device__ inline float clamp_alpha(float raw) { return fminf(fmaxf(raw, 0.01f), 0.99f); }
 struct RecS { float gx, gy, A, B, D, o, r, g, b; };
 
-template <int MODE>
+template <int MODE, int NSALU, int NBR>
 __global__ __launch_bounds__(256) void k(RecS R0, int iters, float *out)
 {
     const int lane = threadIdx.x & 63;
@@ -26,6 +26,17 @@ __global__ __launch_bounds__(256) void k(RecS R0, int iters, float *out)
         R.gy = __int_as_float(__float_as_int(R0.gy) ^ (tw << 1));
         R.o = __int_as_float(__float_as_int(R0.o) ^ tw);
         R.r = __int_as_float(__float_as_int(R0.r) ^ tw);
+        // extra scalar work per entry: NSALU dependent scalar adds, NBR taken scalar branches
+        if (NSALU > 0) {
+            int acc = it;
+#pragma unroll
+            for (int q = 0; q < NSALU; ++q) asm volatile("s_add_i32 %0, %0, 3" : "+s"(acc));
+            R.g = __int_as_float(__float_as_int(R.g) ^ (acc & 1));
+        }
+        if (NBR > 0) {
+#pragma unroll
+            for (int q = 0; q < NBR; ++q) asm volatile("s_cmp_eq_u32 0, 0\n\ts_cbranch_scc1 1f\n\ts_nop 0\n\ts_nop 0\n1:" ::: "scc");
+        }
         if (MODE == 0) {   // full path
             const float dx = R.gx - pxf;
             const float adx2 = R.A * dx * dx;
@@ -59,16 +70,16 @@ __global__ __launch_bounds__(256) void k(RecS R0, int iters, float *out)
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int MODE>
+template <int MODE, int NSALU, int NBR>
 void run(const char *name, float *out)
 {
     const int blocks = 256 * 8, iters = 20000;
     RecS R = {7.3f, 5.1f, -0.02f, 0.003f, -0.015f, 0.7f, 0.5f, 0.4f, 0.3f};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, R, iters, out);
+    hipLaunchKernelGGL((k<MODE, NSALU, NBR>), dim3(blocks), dim3(256), 0, 0, R, iters, out);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, R, iters, out);
+    hipLaunchKernelGGL((k<MODE, NSALU, NBR>), dim3(blocks), dim3(256), 0, 0, R, iters, out);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-18s %8.3f ms  %7.1f cycles per wave-entry per SIMD (at 2.4 GHz)\n", name, ms, ms * 1e-3 * 2.4e9 / (iters * 8.0));
@@ -76,6 +87,9 @@ void run(const char *name, float *out)
 int main()
 {
     float *out; hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
-    run<0>("blend full", out); run<1>("blend clamped-low", out);
+    run<0, 0, 0>("blend full", out); run<1, 0, 0>("blend clamped-low", out);
+    run<0, 30, 0>("full + 30 salu", out); run<1, 30, 0>("low + 30 salu", out);
+    run<0, 0, 4>("full + 4 branches", out); run<1, 0, 4>("low + 4 branches", out);
+    run<0, 30, 4>("full + 30 salu + 4 br", out); run<1, 30, 4>("low + 30 salu + 4 br", out);
     return 0;
 }
