@@ -24,10 +24,12 @@ off = st.tile_offsets.cpu().numpy().astype(np.int64)
 cand = np.nonzero((off[1:] - off[:-1] >= n_list) & (np.arange(len(off) - 1) % nbh_src < nbh_src - 1))[0]
 t0 = int(cand[len(cand) // 2])
 rec = st.stream_rec[off[t0]:off[t0] + n_list].clone()
-rec[:, 0] -= 16.0 * (t0 // nbh_src)
-rec[:, 1] -= 16.0 * (t0 % nbh_src)
-flag_frac = float(((rec[:, 5].view(torch.int32) < 0) & (rec[:, 6].view(torch.int32) < 0)).float().mean())
-one_frac = float(((rec[:, 5].view(torch.int32) < 0) ^ (rec[:, 6].view(torch.int32) < 0)).float().mean())
+rec[:, 1] -= 16.0 * (t0 // nbh_src)   # x
+rec[:, 0] -= 16.0 * (t0 % nbh_src)    # y
+rec[:, 9] = torch.arange(n_list, device=dev, dtype=torch.int32).view(torch.float32)   # slots inside the small pairgrad
+fl = rec[:, 11].view(torch.int32)
+flag_frac = float((fl == 3).float().mean())
+one_frac = float(((fl == 1) | (fl == 2)).float().mean())
 # move the list to tile (0,0) coordinates: every tile sees the same offsets relative to its corner
 stream = rec.repeat(4, 1).contiguous()
 T = (W // 16) * (H // 16)
@@ -40,11 +42,10 @@ view = _lib.make_view(1, 3, W, H, 16, [0.0] * 16, [0.0] * 16, [0.0] * 3)
 img = torch.empty(W, H, 3, device=dev); fT = torch.empty(W, H, device=dev)
 dimg = torch.rand(W, H, 3, device=dev)
 I = 4 * n_list
-pair_slot = torch.arange(I, dtype=torch.int32, device=dev)
 pairgrad = torch.empty(I, 12, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 def fwd(): _lib.check(lib.gsr_composite_fwd(view, tile_offsets.data_ptr(), stream.data_ptr(), img.data_ptr(), fT.data_ptr(), s), "fwd")
-def bwd(): _lib.check(lib.gsr_composite_bwd(view, tile_offsets.data_ptr(), stream.data_ptr(), pair_slot.data_ptr(), fT.data_ptr(), dimg.data_ptr(), I, pairgrad.data_ptr(), s), "bwd")
+def bwd(): _lib.check(lib.gsr_composite_bwd(view, tile_offsets.data_ptr(), stream.data_ptr(), fT.data_ptr(), dimg.data_ptr(), I, pairgrad.data_ptr(), s), "bwd")
 for name, f in (("fwd", fwd), ("bwd", bwd)):
     f(); torch.cuda.synchronize()
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)

@@ -25,13 +25,14 @@ for t in tiles:
     xi, yi = t // nbh, t % nbh
     xs = torch.arange(xi * 16, min(xi * 16 + 16, W), device=dev).float()
     ys = torch.arange(yi * 16, min(yi * 16 + 16, H), device=dev).float()
-    dx = r[:, 0, None, None] - xs[None, :, None]
-    dy = r[:, 1, None, None] - ys[None, None, :]
-    q = r[:, 2, None, None] * dx * dx + r[:, 3, None, None] * dx * dy + r[:, 4, None, None] * dy * dy
-    raw = r[:, 5].abs()[:, None, None] * torch.exp2(q)
+    # stream layout: 0 y, 1 x, 2 D', 3 A', 4 opacity, 5 B', 11 flags
+    dx = r[:, 1, None, None] - xs[None, :, None]
+    dy = r[:, 0, None, None] - ys[None, None, :]
+    q = r[:, 3, None, None] * dx * dx + r[:, 5, None, None] * dx * dy + r[:, 2, None, None] * dy * dy
+    raw = r[:, 4][:, None, None] * torch.exp2(q)
     ps = ((raw >= 0.01) & (raw <= 0.99)).flatten(1)
     anyp = ps.any(1)
-    fl = r[:, 5] < 0
+    fl = r[:, 11].view(torch.int32) == 3
     tot += e - b; flagged += int(fl.sum()); geom += int((~fl & anyp).sum()); nongeom += int((~fl & ~anyp).sum())
     npass.append(ps[~fl & anyp].float().sum(1))
     low = (raw < 0.01)[~fl]                      # [n, x, y]

@@ -18,7 +18,6 @@ for thr in (1e-20, 1e-30, 1e-37, 0.0):
     print("tiles with min T <= %g: %.4f   pixels: %.5f" % (thr, float((Tm <= thr).float().mean()), float((T <= thr).float().mean())))
 print("T quantiles", torch.quantile(T.flatten()[:4000000].float(), torch.tensor([0.001, 0.01, 0.1, 0.5], device=dev)).tolist())
 rec = st.stream_rec[:st.num_pairs]
-print("flagged fraction %.4f" % float((rec[:, 5] < 0).float().mean()))
-top = rec[:, 5].view(torch.int32) < 0; bot = rec[:, 6].view(torch.int32) < 0
+fl = rec[:, 11].view(torch.int32); top = (fl & 1) != 0; bot = (fl & 2) != 0
 print("flags: both %.4f  top only %.4f  bottom only %.4f  none %.4f" % (
     float((top & bot).float().mean()), float((top & ~bot).float().mean()), float((~top & bot).float().mean()), float((~top & ~bot).float().mean())))
