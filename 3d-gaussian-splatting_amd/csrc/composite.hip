@@ -116,7 +116,7 @@ constexpr uint32_t kLowTop = 1u, kLowBottom = 2u, kLowBoth = 3u;
 __device__ inline float clamp_alpha(float raw) { return fminf(fmaxf(raw, kAlphaMin), kAlphaMax); }
 
 // Two pixels per operation.  On gfx950 a v_fma_f32 costs about 4.4 cycles of a SIMD and a
-// v_pk_fma_f32 about 5.6 for two lanes' worth (measured, tools/ubench/valu_rate.hip), so the
+// v_pk_fma_f32 about 5.7 for two lanes' worth (measured, tools/ubench/valu_rate.hip), so the
 // per-pixel fused multiply-adds are written on pairs; a lane's 4 pixels are 2 pairs.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ inline f2 splat(float s) { return f2{s, s}; }

@@ -201,7 +201,8 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": round(dom_ms, 4),
-                "note": "compositing is FP32-VALU/transcendental bound at these list lengths, not HBM bound",
+                "note": "compositing is bound by the vector ALU and the CU's shared scalar unit at these list lengths, not by HBM; "
+                        "traffic = HBM-side bytes of one launch from the PMC passes under profiles/",
             },
             "stage_ms_per_view": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_hbm_frac": {k: round(ab[a] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
