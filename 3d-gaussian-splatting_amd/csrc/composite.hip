@@ -334,7 +334,6 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     const RecordLanes lanes = record_lanes(threadIdx.x & 63);
     // Sums of one entry over the lane's pixels (pairs are added up at the end).
     f2 s_vx, s_vy, s_xx, s_xy, s_yy, s_o, s_r, s_g, s_b;
-    bool any_pass;
 
     // One half of the block with alpha = 0.01 on every pixel: only the transmittance recurrence, the
     // colour sums and the suffix remain; the clamp blocks every geometric gradient.
@@ -398,7 +397,6 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         s_b = pk_fma(wgt, gb[h], s_b);
         // clamp passes gradient on [0.01, 0.99]: exactly when the clamped value equals the input
         const bool p0 = (a.x == raw.x), p1 = (a.y == raw.y);
-        any_pass |= p0 | p1;
         const f2 d_raw = f2{p0 ? d_a.x : 0.0f, p1 ? d_a.y : 0.0f};
         s_o = pk_fma(d_raw, G, s_o);
         const f2 hh = d_raw * a;                       // = -2 dL/d(exponent); a == raw when it matters
@@ -426,27 +424,16 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             return;
         }
         s_vx = s_vy = s_xx = s_xy = s_yy = s_o = z;
-        any_pass = false;
         const float o = R_o(R);
         const float dx = R_gx(R) - pxf;
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
-        if (flags == kLowTop) {
-            half_low(0, R, k, red);
-            half_full(1, R, k, red, o, dx, adx2, bdx);
-        } else if (flags == kLowBottom) {
-            half_full(0, R, k, red, o, dx, adx2, bdx);
-            half_low(1, R, k, red);
-        } else {
-            half_full(0, R, k, red, o, dx, adx2, bdx);
-            half_full(1, R, k, red, o, dx, adx2, bdx);
-        }
-        const bool any_geom = __ballot(any_pass) != 0ull;
-        if (any_geom)
-            reduce_store_full<ATOMIC>(lanes, pairgrad, rec_off, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
-                                      s_yy.x + s_yy.y, s_o.x + s_o.y, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
-        else
-            reduce_store_colour<ATOMIC>(lanes, pairgrad, rec_off, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+        if (flags & kLowTop) half_low(0, R, k, red); else half_full(0, R, k, red, o, dx, adx2, bdx);
+        if (flags & kLowBottom) half_low(1, R, k, red); else half_full(1, R, k, red, o, dx, adx2, bdx);
+        // (an entry that is not flagged but whose clamp blocks every pixel anyway - one in a thousand -
+        // simply stores zero sums)
+        reduce_store_full<ATOMIC>(lanes, pairgrad, rec_off, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
+                                  s_yy.x + s_yy.y, s_o.x + s_o.y, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
     };
     // back to front, two record buffers alternating (see composite_fwd_kernel); k is only needed by
     // the checked variant
