@@ -75,14 +75,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # GSR_BENCH_FORCE_DIST=1 rehearses the multi-rank code path (process group, all-reduce, barrier,
+    # max over ranks) with a single rank, e.g. under torchrun --nproc-per-node 1
+    use_dist = world > 1 or (os.environ.get("GSR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the render path has no CPU implementation)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.views % world != 0:
         raise SystemExit(f"--views {args.views} must be a multiple of the number of ranks {world}")
@@ -120,10 +123,13 @@ def main():
             states.append(st)
             gsums.append(backward_records(st, cot))
         backward_views(states, gsums, *params, grads=tuple(grads))
-        bucket.all_reduce()
+        if use_dist and world == 1:
+            dist.all_reduce(bucket.flat)      # rehearsal: GradBucket skips the collective for one rank
+        else:
+            bucket.all_reduce()
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -146,7 +152,7 @@ def main():
         sync()
     stage = timer.summary()
     breakdown_steps = 2
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -215,7 +221,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cams[0], args)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
