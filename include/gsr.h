@@ -184,6 +184,22 @@ int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets,
                       const float *stream_rec, const float *final_T, const float *dimg,
                       uint32_t num_pairs, float *pairgrad, void *stream);
 
+/* ---- training loss of one view ----------------------------------------------------------
+ * Replaces Trainer.compute_loss (Trainer.py:35-38) with its two terms l1_loss (Utils/Loss.py:4-5)
+ * and ssim_loss (Utils/Loss.py:59-97) and their autograd, for pred and gt of shape [W,H,3] as the
+ * renderer and the data loader (Utils/DataLoader.py:81-89) hand them over:
+ *   loss = (1 - loss_lambda) * mean|pred - gt| + loss_lambda * (1 - ssim).
+ * As in the reference, the SSIM window code takes dimension -3 of a [W,H,3] tensor as the channel
+ * count (Utils/Loss.py:70): each image column x is one [H,3] plane, and the 11x11 Gaussian window
+ * (sigma 1.5, zero padding 5) runs along y and across the three colours.
+ * out[3] (device) = {loss, l1, ssim}.  dpred[W,H,3] (device, may be NULL) = grad_scale * dloss/dpred,
+ * fully overwritten; loss_lambda = 0 gives the gradient of l1_loss, loss_lambda = 1 with
+ * grad_scale = -1 that of ssim_loss.  workspace: gsr_loss_workspace_bytes(width, height). */
+size_t gsr_loss_workspace_bytes(int width, int height);
+int gsr_loss_fwd_bwd(const float *pred, const float *gt, int width, int height, float loss_lambda,
+                     float grad_scale, float *out, float *dpred, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ class GsoView(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("gso_oracle.c", "gso_composite.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("gso_oracle.c", "gso_loss.c", "gso_composite.inc")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libgso_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -141,6 +141,22 @@ def render_scene(scene, tile_length, dimg=None, threads=None, screen_coords=None
                   scene.opacity.numpy(), scene.sh.numpy(), scene.sh_degree, scene.width, scene.height,
                   tile_length, cam.w2m_host, cam.proj_host, np.asarray(scene.cam_position, np.float32),
                   screen_coords=screen_coords, dimg=dimg, threads=threads, precise=precise)
+
+
+def loss(pred, gt, w_l1=0.8, w_ssim=-0.2, want_grad=True):
+    """l1 (Utils/Loss.py:4-5), mean SSIM over [W,H,3] read as W planes of [H,3] (Utils/Loss.py:69-97),
+    and ``w_l1 * d l1/d pred + w_ssim * d ssim/d pred``.  The reference's training loss
+    (Trainer.py:35-38) is ``(1 - lam) * l1 + lam * (1 - ssim)``, i.e. weights ``(1 - lam, -lam)``."""
+    L = lib()
+    pred, gt = _f32(pred), _f32(gt)
+    assert pred.shape == gt.shape and pred.ndim == 3 and pred.shape[2] == 3
+    w, h = pred.shape[:2]
+    out = np.zeros(2, np.float64)
+    dpred = np.zeros_like(pred) if want_grad else None
+    rc = L.gso_loss(_p(pred), _p(gt), C.c_int(w), C.c_int(h), C.c_double(w_l1), C.c_double(w_ssim), _p(out), _p(dpred))
+    if rc != 0:
+        raise ValueError("bad argument")
+    return {"l1": float(out[0]), "ssim": float(out[1]), "dpred": dpred}
 
 
 def max_threads() -> int:

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from util import assert_bit_equal, assert_close, golden_names, load_golden
+from util import assert_bit_equal, assert_close, golden_names, load_golden, loss_golden_names
 
 GRADS = ("g_coords", "g_scale", "g_rotation", "g_opacity", "g_sh", "g_screen")
 
@@ -73,3 +73,27 @@ def test_oracle_thread_count_invariance(oracle_mod):
     assert_bit_equal(a["tile_lists"], b["tile_lists"], "lists")
     for k in GRADS:
         assert_close(a[k], b[k], k, rtol=1e-6, atol_frac=1e-9)
+
+
+@pytest.mark.parametrize("name", loss_golden_names())
+def test_loss_oracle_matches_reference(oracle_mod, name):
+    """The loss oracle against the reference's own l1_loss / ssim_loss and autograd (Utils/Loss.py,
+    combined as in Trainer.py:35-38)."""
+    g = load_golden(name)
+    lam = float(g["loss_lambda"])
+    o = oracle_mod.loss(g["pred"], g["gt"], 1.0 - lam, -lam)
+    assert_close(o["l1"], g["ref_l1"], "l1", rtol=1e-6, atol_frac=0)
+    assert_close(o["ssim"], g["ref_ssim"], "ssim", rtol=1e-5, atol_frac=0)
+    loss = (1.0 - lam) * o["l1"] + lam * (1.0 - o["ssim"])
+    assert_close(loss, g["ref_loss"], "loss", rtol=1e-6, atol_frac=0)
+    assert_close(o["dpred"], g["ref_dpred"], "dloss/dpred")
+
+
+def test_loss_fixture_coverage():
+    names = loss_golden_names()
+    assert len(names) >= 7
+    shapes = [load_golden(n)["pred"].shape for n in names]
+    assert any(s[1] < 11 for s in shapes)            # fewer rows than the window
+    assert any(s[0] == 1 for s in shapes)            # a single image column
+    assert any(load_golden(n)["gt"].max() > 200 for n in names)   # 0..255 targets (Utils/DataLoader.py:83)
+    assert any((load_golden(n)["pred"] == load_golden(n)["gt"]).mean() > 0.1 for n in names)   # ties

@@ -13,8 +13,18 @@ RTOL = 1e-4
 ATOL_FRAC = 2e-6
 
 
-def golden_names():
+def _names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def golden_names():
+    """Fixtures of the render path (tests/golden/make_golden.py)."""
+    return [n for n in _names() if not n.startswith("loss_")]
+
+
+def loss_golden_names():
+    """Fixtures of the training loss (tests/golden/make_loss_golden.py)."""
+    return [n for n in _names() if n.startswith("loss_")]
 
 
 def load_golden(name):
