@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 import gsplat_amd  # noqa: E402,F401
 from gsplat_amd.camera import Camera  # noqa: E402
 from gsplat_amd.minibatch import GradBucket, shard_views  # noqa: E402
+from gsplat_amd.loss import loss_and_grad  # noqa: E402
 from gsplat_amd.rasterizer import (StageTimer, ViewSpec, backward_records, backward_views, forward_begin,  # noqa: E402
                                    forward_finish)
 from gsplat_amd.scenes import synthetic_scene  # noqa: E402
@@ -70,6 +71,9 @@ def main():
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-loss", action="store_true",
+                    help="dL/dimg of each view from the training loss 0.8*L1 + 0.2*(1-SSIM) against a synthetic "
+                         "0..255 target (one more kernel per view) instead of a fixed cotangent")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,6 +104,10 @@ def main():
     # dL/dimg of loss = mean over the minibatch of sum(img * R_v)
     cots = [(torch.rand(args.width, args.height, 3, generator=gen) / args.views).to(dev) for _ in range(args.views)]
     cots = [cots[v] for v in my_views]
+    targets = None
+    if args.with_loss:
+        targets = [torch.floor(torch.rand(args.width, args.height, 3, generator=gen) * 256).to(dev) for _ in range(args.views)]
+        targets = [targets[v] for v in my_views]
 
     # one flat fp32 bucket for the five parameter gradients (59 floats per Gaussian)
     bucket = GradBucket(n, dev)
@@ -121,6 +129,8 @@ def main():
             if i == 0:
                 stats.update(m=st.num_visible, pairs=st.num_pairs)
             states.append(st)
+            if targets is not None:    # loss = mean over the minibatch of the per-view training loss
+                _, cot = loss_and_grad(st.img, targets[i], 0.2, 1.0 / args.views)
             gsums.append(backward_records(st, cot))
         backward_views(states, gsums, *params, grads=tuple(grads))
         if use_dist and world == 1:
@@ -197,7 +207,8 @@ def main():
             "config": {
                 "workload": f"{n} synthetic Gaussians, SH degree {args.sh_degree}, {args.width}x{args.height}, "
                             f"tile {args.tile}, {args.views}-view minibatch fwd+bwd split over {world} GPU(s), "
-                            + ("RCCL all-reduce of the 59N-float gradient bucket" if world > 1 else "no collective"),
+                            + ("RCCL all-reduce of the 59N-float gradient bucket" if world > 1 else "no collective")
+                            + (", dL/dimg from the training loss kernel" if args.with_loss else ""),
                 "gaussians": n, "width": args.width, "height": args.height, "tile_length": args.tile,
                 "sh_degree": args.sh_degree, "views_per_step": args.views,
                 "visible": stats.get("m"), "pairs_per_view": pairs,
