@@ -16,6 +16,7 @@ REC_FLOATS = 12
 STREAM_DWORDS = 16
 PAIRGRAD_FLOATS = 12
 MAX_VIEWS = 8
+ADAM_MAX_TENSORS = 8
 
 # Every symbol include/gsr.h declares.
 SYMBOLS = (
@@ -25,6 +26,9 @@ SYMBOLS = (
     "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_lists_workspace_bytes", "gsr_bin_lists",
     "gsr_composite_fwd", "gsr_composite_bwd",
     "gsr_loss_workspace_bytes", "gsr_loss_fwd_bwd",
+    "gsr_adam_step",
+    "gsr_densify_stats", "gsr_densify_select_workspace_bytes", "gsr_densify_select", "gsr_densify_apply",
+    "gsr_remove_select_workspace_bytes", "gsr_remove_select", "gsr_remove_apply_workspace_bytes", "gsr_remove_apply",
 )
 
 
@@ -74,7 +78,9 @@ def load():
             raise RuntimeError(f"{LIB_PATH} does not export {name}")
     lib.gsr_last_error.restype = C.c_char_p
     for name in ("gsr_sort_workspace_bytes", "gsr_scan_workspace_bytes", "gsr_bin_offsets_workspace_bytes",
-                 "gsr_bin_lists_workspace_bytes", "gsr_preprocess_bwd_workspace_bytes"):
+                 "gsr_bin_lists_workspace_bytes", "gsr_preprocess_bwd_workspace_bytes",
+                 "gsr_densify_select_workspace_bytes", "gsr_remove_select_workspace_bytes",
+                 "gsr_remove_apply_workspace_bytes"):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.c_uint32]
     vp = C.c_void_p
@@ -93,6 +99,13 @@ def load():
     lib.gsr_loss_workspace_bytes.restype = C.c_size_t
     lib.gsr_loss_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.gsr_loss_fwd_bwd.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_adam_step.argtypes = ([C.c_uint32] + [C.POINTER(vp)] * 4 + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)] +
+                                  [C.c_double] * 4 + [vp])
+    lib.gsr_densify_stats.argtypes = [C.c_uint32, vp, vp, vp, vp, vp]
+    lib.gsr_densify_select.argtypes = [C.c_uint32, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_densify_apply.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32] + [vp] * 9 + [vp]
+    lib.gsr_remove_select.argtypes = [C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_remove_apply.argtypes = [C.c_uint32, C.c_uint32] + [vp] * 9 + [vp, C.c_size_t, vp]
     _lib = lib
     return lib
 

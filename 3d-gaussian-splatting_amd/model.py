@@ -41,3 +41,69 @@ class GaussianParams(nn.Module):
     def raw(self):
         n = self._size
         return self._coords[:n], self._scale[:n], self._rotation[:n], self._opacity[:n], self._sh[:n]
+
+
+class GaussianModel(GaussianParams):
+    """The reference ``GaussianModel``'s training-state surface (``GaussianModel.py:14-245``) on the
+    GPU: capacity rows of which ``_size`` are live, the densification statistics and the methods the
+    trainer calls around a render (``Trainer.py:60-74``).  Each method does what the reference's
+    method of the same name does, through the kernels behind ``densify.py``.  Point-cloud
+    construction and PLY I/O are not part of it."""
+
+    def __init__(self, coords, scale, rotation, opacity, sh, sh_degree: int = 0, max_sh_degree: int = 3, size=None):
+        super().__init__(coords, scale, rotation, opacity, sh, sh_degree, max_sh_degree)
+        cap = coords.shape[0]
+        self._size = cap if size is None else int(size)
+        self._device = coords.device
+        self._coords_grads = torch.zeros((cap, 1), dtype=torch.float32, device=coords.device)
+        self._denom = torch.zeros((cap, 1), dtype=torch.int32, device=coords.device)
+
+    @property
+    def capacity(self):
+        return self._coords.shape[0]
+
+    # activated views, GaussianModel.py:50-65 (the renderer itself reads the raw tensors)
+    @property
+    def scale(self):
+        return torch.exp(self._scale[:self._size])
+
+    @property
+    def rotation(self):
+        return torch.nn.functional.normalize(self._rotation[:self._size])
+
+    @property
+    def opacity(self):
+        return torch.sigmoid(self._opacity[:self._size])
+
+    @property
+    def sh(self):
+        return self._sh[:self._size, :, :(self.curr_sh_degree + 1) ** 2]
+
+    def reset_opacity(self):
+        from . import densify as D
+        D.reset_opacity(self)
+
+    def add_sh_degree(self):
+        from . import densify as D
+        D.add_sh_degree(self)
+
+    def expand_capacity(self, new_capacity: int):
+        from . import densify as D
+        D.expand_capacity(self, new_capacity)
+
+    def update_densify_stats(self, pos2d, mask):
+        from . import densify as D
+        D.update_densify_stats(self, pos2d, mask)
+
+    def densify(self, scene_radius, noise=None, generator=None):
+        from . import densify as D
+        return D.densify(self, scene_radius, noise=noise, generator=generator)
+
+    def remove(self, mask, inplace: bool = True):
+        from . import densify as D
+        return D.remove(self, mask, inplace)
+
+    def capture(self, optimizer):
+        """``GaussianModel.capture`` (``GaussianModel.py:320-331``)."""
+        return (self.curr_sh_degree, self._coords, self._sh, self._scale, self._rotation, self._opacity,
+                self._coords_grads, self._denom, optimizer.state_dict())

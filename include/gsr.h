@@ -200,6 +200,73 @@ int gsr_loss_fwd_bwd(const float *pred, const float *gt, int width, int height, 
                      float grad_scale, float *out, float *dpred, void *workspace,
                      size_t workspace_bytes, void *stream);
 
+/* ---- optimiser step ------------------------------------------------------------------------
+ * Replaces optimizer.step() (Trainer.py:80) of the torch.optim.Adam built at Trainer.py:24
+ * (lr, betas; eps 1e-8, no weight decay, no amsgrad) for up to GSR_ADAM_MAX_TENSORS tensors in one
+ * launch.  The *_host arguments are HOST arrays of num_tensors entries: device pointers of the
+ * parameter, its gradient and its two moment buffers (exp_avg, exp_avg_sq: zeros before the first
+ * step), the element counts, and the 1-based count of THIS step per tensor (a tensor that had no
+ * gradient in some iteration is left out of that call and keeps its count, as PyTorch does).
+ * Per element: m = lerp(m, g, 1-beta1); v = v*beta2 + (1-beta2)*g*g;
+ * p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps). */
+#define GSR_ADAM_MAX_TENSORS 8
+int gsr_adam_step(uint32_t num_tensors, float *const *param_host, const float *const *grad_host,
+                  float *const *exp_avg_host, float *const *exp_avg_sq_host, const uint64_t *numel_host,
+                  const uint32_t *step_host, double lr, double beta1, double beta2, double eps, void *stream);
+
+/* ---- densification bookkeeping --------------------------------------------------------------
+ * Rows are the reference's parameter rows of a model with `size` live rows inside tensors of
+ * `capacity` rows: coords[.,3] scale_raw[.,3] rot_raw[.,4] opac_raw[.,1] sh[.,3,16], plus the
+ * statistics coords_grads[.,1] f32 and denom[.,1] i32 (GaussianModel.py:19-26,93-94). */
+
+/* GaussianModel.update_densify_stats (GaussianModel.py:230-232): for the n live rows,
+ * coords_grads[i] += |g_screen[i, :2]| and denom[i] += 1 where mask[i]. */
+int gsr_densify_stats(uint32_t n, const uint8_t *mask, const float *g_screen, float *coords_grads,
+                      int32_t *denom, void *stream);
+
+/* Selection of GaussianModel.densify (GaussianModel.py:236-244): with g = coords_grads / denom
+ * (nan -> 0) and s = the largest RAW scale of the row, row i < size is cloned when
+ * |g| >= grad_threshold and s <= scale_threshold, split when |g| >= grad_threshold and
+ * s > scale_threshold (the reference passes 0.0002 and 0.01 * scene_radius).
+ * Outputs: cls[size] u8 (0 none, 1 clone, 2 split), clone_rank[size] / split_rank[size] = number of
+ * cloned / split rows below i, counts[2] (device) = {num_clone, num_split}. */
+size_t gsr_densify_select_workspace_bytes(uint32_t size);
+int gsr_densify_select(uint32_t size, const float *coords_grads, const int32_t *denom, const float *scale_raw,
+                       float grad_threshold, float scale_threshold, uint8_t *cls, uint32_t *clone_rank,
+                       uint32_t *split_rank, uint32_t *counts, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
+/* GaussianModel.clone (GaussianModel.py:189-193) followed by GaussianModel.split
+ * (GaussianModel.py:209-224, split_factor 2) for the selection above; the tensors must hold at
+ * least size + num_clone + num_split rows (the caller grows them as GaussianModel.py:184-187,
+ * 204-207 do).  Cloned row i is copied to row size + clone_rank[i].  Split row i, with k =
+ * split_rank[i], std = exp(scale_raw[i]) and R = the rotation matrix of its normalised quaternion,
+ * gets coords = R (noise[k] * std) and the new row size + num_clone + k gets
+ * coords = R (noise[num_split + k] * std); both get scale_raw = log(std / 1.6); the new row copies
+ * rotation, opacity and sh.  noise[2 * num_split, 3]: the standard-normal draws behind the
+ * reference's torch.normal(0, std) (GaussianModel.py:210), supplied by the caller.  As in the
+ * reference the old centre is not added to the new centres. */
+int gsr_densify_apply(uint32_t size, uint32_t num_clone, uint32_t num_split, const uint8_t *cls,
+                      const uint32_t *clone_rank, const uint32_t *split_rank, const float *noise,
+                      float *coords, float *scale_raw, float *rot_raw, float *opac_raw, float *sh,
+                      void *stream);
+
+/* GaussianModel.remove(mask, inplace=True) (GaussianModel.py:148-164), literally: with r = the
+ * number of set mask bytes, the last r KEPT rows (in order) are written to rows
+ * [size - 2r, size - r) - opacity, rotation and scale in their activated form (sigmoid, normalised,
+ * exp), coords, sh and the statistics as they are - and the caller then lowers the size by r.
+ * gsr_remove_select: keep_rank[i] = number of kept rows below i, *num_kept (device) = size - r.
+ * gsr_remove_apply: needs the num_removed read back from that; fails when 2 r > size (the
+ * reference raises there). */
+size_t gsr_remove_select_workspace_bytes(uint32_t size);
+int gsr_remove_select(uint32_t size, const uint8_t *mask, uint32_t *keep_rank, uint32_t *num_kept,
+                      void *workspace, size_t workspace_bytes, void *stream);
+size_t gsr_remove_apply_workspace_bytes(uint32_t num_removed);
+int gsr_remove_apply(uint32_t size, uint32_t num_removed, const uint8_t *mask, const uint32_t *keep_rank,
+                     float *coords, float *scale_raw, float *rot_raw, float *opac_raw, float *sh,
+                     float *coords_grads, int32_t *denom, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

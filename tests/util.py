@@ -19,7 +19,8 @@ def _names():
 
 def golden_names():
     """Fixtures of the render path (tests/golden/make_golden.py)."""
-    return [n for n in _names() if not n.startswith("loss_")]
+    other = ("loss_", "adam_", "stats_", "densify_", "remove_")   # fixtures of the loss and of the training-state updates
+    return [n for n in _names() if not n.startswith(other)]
 
 
 def loss_golden_names():
