@@ -44,10 +44,18 @@ def update_densify_stats(model, pos2d: torch.Tensor, mask: torch.Tensor):
         raise RuntimeError("screen_coords has no gradient: call backward() first")
     if tuple(g.shape) != (n, 3) or not g.is_cuda:
         raise ValueError(f"screen_coords.grad has shape {tuple(g.shape)}, expected [{n},3] on the GPU")
+    accumulate_stats(model, g, mask)
+
+
+@torch.no_grad()
+def accumulate_stats(model, g_screen: torch.Tensor, mask: torch.Tensor):
+    """The same from the gradient tensor itself (``[size,3]``), e.g. a view's ``g_screen`` as
+    ``rasterizer.backward_views`` returns it."""
+    n = int(model._size)
     m8 = _mask_u8(mask, n)
     lib = _lib.load()
-    _call("gsr_densify_stats", lib.gsr_densify_stats, n, m8.data_ptr(), g.contiguous().data_ptr(),
-          model._coords_grads.data_ptr(), model._denom.data_ptr(), _stream(g.device))
+    _call("gsr_densify_stats", lib.gsr_densify_stats, n, m8.data_ptr(), g_screen.contiguous().data_ptr(),
+          model._coords_grads.data_ptr(), model._denom.data_ptr(), _stream(g_screen.device))
 
 
 @torch.no_grad()

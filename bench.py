@@ -74,7 +74,12 @@ def main():
     ap.add_argument("--with-loss", action="store_true",
                     help="dL/dimg of each view from the training loss 0.8*L1 + 0.2*(1-SSIM) against a synthetic "
                          "0..255 target (one more kernel per view) instead of a fixed cotangent")
+    ap.add_argument("--train-iter", action="store_true",
+                    help="a full training iteration per step: --with-loss plus the densification statistics of every "
+                         "view and one fused Adam step on the gradient bucket (Trainer.py:53-80 for a view minibatch)")
     args = ap.parse_args()
+    if args.train_iter:
+        args.with_loss = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,6 +119,14 @@ def main():
     grads = list(bucket.views)
 
     stats = {}
+    model = opt = None
+    if args.train_iter:
+        from gsplat_amd.densify import accumulate_stats
+        from gsplat_amd.model import GaussianModel
+        from gsplat_amd.optimizer import Adam
+        model = GaussianModel(*params, sh_degree=args.sh_degree)
+        params = [model._coords.data, model._scale.data, model._rotation.data, model._opacity.data, model._sh.data]
+        opt = Adam(params, lr=1e-3, betas=(0.5, 0.999))      # Trainer.py:15-16,24
 
     def step():
         # 1. stage 1 + depth order of every view of the rank, enqueued back to back (no host wait);
@@ -132,11 +145,17 @@ def main():
             if targets is not None:    # loss = mean over the minibatch of the per-view training loss
                 _, cot = loss_and_grad(st.img, targets[i], 0.2, 1.0 / args.views)
             gsums.append(backward_records(st, cot))
-        backward_views(states, gsums, *params, grads=tuple(grads))
+        _, g_screens = backward_views(states, gsums, *params, grads=tuple(grads))
         if use_dist and world == 1:
             dist.all_reduce(bucket.flat)      # rehearsal: GradBucket skips the collective for one rank
         else:
             bucket.all_reduce()
+        if opt is not None:
+            # (each rank gathers the statistics of its own views; a trainer sums them over the ranks
+            # before it densifies, every 50 iterations)
+            for st, gs in zip(states, g_screens):
+                accumulate_stats(model, gs, st.mask_u8)
+            opt.step(grads=bucket.views)
 
     def sync():
         if use_dist:
@@ -208,7 +227,8 @@ def main():
                 "workload": f"{n} synthetic Gaussians, SH degree {args.sh_degree}, {args.width}x{args.height}, "
                             f"tile {args.tile}, {args.views}-view minibatch fwd+bwd split over {world} GPU(s), "
                             + ("RCCL all-reduce of the 59N-float gradient bucket" if world > 1 else "no collective")
-                            + (", dL/dimg from the training loss kernel" if args.with_loss else ""),
+                            + (", dL/dimg from the training loss kernel" if args.with_loss else "")
+                            + (", densification statistics and fused Adam step" if args.train_iter else ""),
                 "gaussians": n, "width": args.width, "height": args.height, "tile_length": args.tile,
                 "sh_degree": args.sh_degree, "views_per_step": args.views,
                 "visible": stats.get("m"), "pairs_per_view": pairs,
