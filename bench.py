@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--with-loss", action="store_true",
                     help="dL/dimg of each view from the training loss 0.8*L1 + 0.2*(1-SSIM) against a synthetic "
                          "0..255 target (one more kernel per view) instead of a fixed cotangent")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="render only, no backward and no collective (the forward-only stress configuration, e.g. "
+                         "--gaussians 6000000 --width 3840 --height 2160)")
     ap.add_argument("--train-iter", action="store_true",
                     help="a full training iteration per step: --with-loss plus the densification statistics of every "
                          "view and one fused Adam step on the gradient bucket (Trainer.py:53-80 for a view minibatch)")
@@ -142,9 +145,13 @@ def main():
             if i == 0:
                 stats.update(m=st.num_visible, pairs=st.num_pairs)
             states.append(st)
+            if args.forward_only:
+                continue
             if targets is not None:    # loss = mean over the minibatch of the per-view training loss
                 _, cot = loss_and_grad(st.img, targets[i], 0.2, 1.0 / args.views)
             gsums.append(backward_records(st, cot))
+        if args.forward_only:
+            return
         _, g_screens = backward_views(states, gsums, *params, grads=tuple(grads))
         if use_dist and world == 1:
             dist.all_reduce(bucket.flat)      # rehearsal: GradBucket skips the collective for one rank
@@ -167,7 +174,8 @@ def main():
     sync()
     # Timed region: only the dominant kernel's entry point is bracketed by HIP events (on the stream it
     # is launched on); timing every call costs about 2.5 % of the step.
-    with StageTimer(only=("gsr_composite_bwd",)) as timer:
+    dom = "composite_fwd" if args.forward_only else "composite_bwd"
+    with StageTimer(only=("gsr_" + dom,)) as timer:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -197,7 +205,6 @@ def main():
         views_timed = max(len(views), 1) * breakdown_steps
         stage_ms = {k.replace("gsr_", ""): v[1] / views_timed for k, v in stage.items()}
         stage_ms["preprocess_bwd"] = stage_ms.get("pair_reduce", 0.0) + stage_ms.get("preprocess_bwd_views", 0.0)
-        dom = "composite_bwd"
         calls, total_ms = dominant.get("gsr_" + dom, (0, float("nan")))
         dom_ms = total_ms / max(calls, 1)      # average launch duration over the timed region
         stage_ms[dom] = dom_ms
@@ -225,8 +232,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{n} synthetic Gaussians, SH degree {args.sh_degree}, {args.width}x{args.height}, "
-                            f"tile {args.tile}, {args.views}-view minibatch fwd+bwd split over {world} GPU(s), "
-                            + ("RCCL all-reduce of the 59N-float gradient bucket" if world > 1 else "no collective")
+                            f"tile {args.tile}, {args.views}-view minibatch {'forward only' if args.forward_only else 'fwd+bwd'} split over {world} GPU(s), "
+                            + ("RCCL all-reduce of the 59N-float gradient bucket" if world > 1 and not args.forward_only else "no collective")
                             + (", dL/dimg from the training loss kernel" if args.with_loss else "")
                             + (", densification statistics and fused Adam step" if args.train_iter else ""),
                 "gaussians": n, "width": args.width, "height": args.height, "tile_length": args.tile,
@@ -234,7 +241,7 @@ def main():
                 "visible": stats.get("m"), "pairs_per_view": pairs,
             },
             "roofline": {
-                "kernel": "composite_bwd_kernel", "bound": "hbm",
+                "kernel": dom + "_kernel", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": round(dom_ms, 4),
@@ -245,9 +252,9 @@ def main():
             "stage_hbm_frac": {k: round(ab[a] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                for k, a in (("preprocess_fwd", "preprocess_fwd"), ("composite_fwd", "composite_fwd"),
                                             ("composite_bwd", "composite_bwd"), ("preprocess_bwd", "preprocess_bwd"))
-                               if k in stage_ms},
+                               if stage_ms.get(k, 0.0) > 0.0},
         }
-        if flops_bwd:
+        if flops_bwd and not args.forward_only:
             out["roofline"]["valu_frac_algorithmic"] = round(flops_bwd / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cams[0], args)

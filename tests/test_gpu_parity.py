@@ -212,6 +212,20 @@ def test_config3_1m_1080p_vs_oracle(oracle_mod):
     assert np.array_equal(np.bincount(lst, minlength=len(bb)), (nx * ny) * hip["mask"])
 
 
+def test_config5_6m_4k_forward_vs_oracle(oracle_mod):
+    """BASELINE config 5 (stress), one view at full size: 6 M Gaussians, 3840x2160, tile 16, forward
+    only (32 M pairs, a 2 GiB record stream): discrete results bit-exact, the image within tolerance."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.scenes import synthetic_scene
+    sc = synthetic_scene(6_000_000, 3840, 2160, 3, 0)
+    a = _scene_arrays(sc)
+    hip = run_hip(tile=16, **a)
+    assert hip["num_pairs"] > 30_000_000
+    ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 3, 3840, 2160, 16,
+                            a["w2m"], a["proj"], a["cam_pos"])
+    compare(hip, ora)
+
+
 def test_huge_splats_cover_every_tile(oracle_mod):
     """Gaussians that land in thousands of tiles: the per-Gaussian record sums take the wave-cooperative path."""
     import gsplat_amd  # noqa: F401
