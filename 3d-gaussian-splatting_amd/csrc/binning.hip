@@ -181,7 +181,68 @@ inline int bits_for(uint32_t count)
     return b;
 }
 
+// ---- order in which the compositing grid takes the tiles ------------------------------------------
+// One wave composites one 16x16 block over its tile's whole list, lists differ in length by a factor
+// of twenty within a view, and the grid is only one to two rounds of resident waves: in tile-id
+// order the waves still running at the end are whichever long lists came late.  Longest lists first
+// keeps the drain short.  A counting sort over 1024 length classes (exact order inside a class does
+// not matter) by one workgroup: T is a few thousand to a few hundred thousand.
+constexpr int kOrderThreads = 1024;
+constexpr int kOrderBuckets = 1024;
+
+__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(uint32_t T, const uint32_t *__restrict__ tile_offsets,
+                                                                   uint32_t *__restrict__ tile_order)
+{
+    __shared__ uint32_t s_count[kOrderBuckets];
+    __shared__ uint32_t s_max[kOrderThreads / GSR_WAVE];
+    const uint32_t t = threadIdx.x;
+    uint32_t mx = 0;
+    for (uint32_t i = t; i < T; i += kOrderThreads) mx = max(mx, tile_offsets[i + 1] - tile_offsets[i]);
+    for (int m = 32; m >= 1; m >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m));
+    if ((t & 63) == 0) s_max[t >> 6] = mx;
+    s_count[t] = 0;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < kOrderThreads / GSR_WAVE; ++w) mx = max(mx, s_max[w]);
+    // class 0 holds the longest lists
+    const float to_class = (float)(kOrderBuckets - 1) / (float)max(mx, 1u);
+    auto class_of = [&](uint32_t len) {
+        const int c = (kOrderBuckets - 1) - (int)((float)len * to_class);
+        return (uint32_t)min(max(c, 0), kOrderBuckets - 1);
+    };
+    for (uint32_t i = t; i < T; i += kOrderThreads) atomicAdd(&s_count[class_of(tile_offsets[i + 1] - tile_offsets[i])], 1u);
+    __syncthreads();
+    // exclusive scan of the 1024 class counts: one per thread
+    const uint32_t mine = s_count[t];
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if ((int)(t & 63) >= d) incl += up;
+    }
+    __syncthreads();
+    if ((t & 63) == 63) s_max[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (t >> 6); ++w) base += s_max[w];
+    s_count[t] = base + incl - mine;
+    __syncthreads();
+    for (uint32_t i = t; i < T; i += kOrderThreads) {
+        const uint32_t pos = atomicAdd(&s_count[class_of(tile_offsets[i + 1] - tile_offsets[i])], 1u);
+        tile_order[pos] = i;
+    }
+}
+
 }  // namespace
+
+extern "C" int gsr_tile_order(const gsr_view *view_host, const uint32_t *tile_offsets, uint32_t *tile_order, void *stream)
+{
+    ViewK v;
+    if (int e = gsr_make_view(view_host, &v)) return e;
+    if (!tile_offsets || !tile_order) { gsr_set_error("gsr_tile_order: null pointer"); return GSR_ERR_ARG; }
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, (hipStream_t)stream, (uint32_t)v.T, tile_offsets,
+                       tile_order);
+    return gsr_check_launch("tile_order");
+}
 
 extern "C" size_t gsr_bin_offsets_workspace_bytes(uint32_t n)
 {

@@ -37,15 +37,19 @@ struct WaveGeom {
     uint32_t total;      // records in the whole stream
 };
 
-__device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ tile_offsets, WaveGeom &w)
+// tile_order (may be null): the tiles in the order in which the waves of the grid take them - longest
+// lists first, so that the waves still running when the grid drains are short ones.
+__device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ tile_offsets,
+                                  const uint32_t *__restrict__ tile_order, WaveGeom &w)
 {
     const int S = (v.L + 15) >> 4;
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned wv = blockIdx.x * WAVES_PER_BLOCK + wave_in_block;
     const unsigned per_tile = (unsigned)(S * S);
-    const unsigned tile = wv / per_tile;
-    if (tile >= (unsigned)v.T) return false;
-    const unsigned sub = wv - tile * per_tile;
+    const unsigned turn = wv / per_tile;
+    if (turn >= (unsigned)v.T) return false;
+    const unsigned sub = wv - turn * per_tile;
+    const unsigned tile = tile_order ? tile_order[turn] : turn;
     const int sxi = (int)(sub / (unsigned)S), syi = (int)(sub - (unsigned)sxi * S);
     const int xi = (int)(tile / (unsigned)v.nbh), yi = (int)(tile - (unsigned)xi * v.nbh);
     const int lane = threadIdx.x & 63;
@@ -125,11 +129,12 @@ __device__ inline f2 exp2_2(f2 q) { return f2{__builtin_amdgcn_exp2f(q.x), __bui
 __device__ inline f2 clamp_alpha2(f2 raw) { return f2{clamp_alpha(raw.x), clamp_alpha(raw.y)}; }
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
+                                                            const uint32_t *__restrict__ tile_order,
                                                             const float *__restrict__ stream_rec,
                                                             float *__restrict__ img, float *__restrict__ final_T)
 {
     WaveGeom w;
-    if (!wave_setup(v, tile_offsets, w)) return;
+    if (!wave_setup(v, tile_offsets, tile_order, w)) return;
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], cr[2], cg[2], cb[2];   // pixel rows (y0, y0+4): top half, (y0+8, y0+12): bottom half
 #pragma unroll
@@ -474,13 +479,14 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
 // does not pay (in registers, hence in waves per SIMD) for the rarely needed checked one.
 template <bool TINY, bool ATOMIC>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
+                                                            const uint32_t *__restrict__ tile_order,
                                                             const float *__restrict__ stream_rec,
                                                             const float *__restrict__ final_T,
                                                             const float *__restrict__ dimg,
                                                             float *__restrict__ pairgrad)
 {
     WaveGeom w;
-    if (!wave_setup(v, tile_offsets, w)) return;
+    if (!wave_setup(v, tile_offsets, tile_order, w)) return;
     if (w.begin >= w.end) return;
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], gr[2], gg[2], gb[2];
@@ -542,8 +548,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
 
 }  // namespace
 
-extern "C" int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets, const float *stream_rec,
-                                 float *img, float *final_T, void *stream)
+extern "C" int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets, const uint32_t *tile_order,
+                                 const float *stream_rec, float *img, float *final_T, void *stream)
 {
     ViewK v;
     if (int e = gsr_make_view(view_host, &v)) return e;
@@ -551,13 +557,13 @@ extern "C" int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile
     const int S = (v.L + 15) >> 4;
     const unsigned waves = (unsigned)v.T * S * S;
     hipLaunchKernelGGL(composite_fwd_kernel, dim3(gsr_div_up(waves, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, v, tile_offsets, stream_rec, img, final_T);
+                       (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, img, final_T);
     return gsr_check_launch("composite_fwd");
 }
 
-extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, const float *stream_rec,
-                                 const float *final_T, const float *dimg, uint32_t num_pairs, float *pairgrad,
-                                 void *stream)
+extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, const uint32_t *tile_order,
+                                 const float *stream_rec, const float *final_T, const float *dimg, uint32_t num_pairs,
+                                 float *pairgrad, void *stream)
 {
     ViewK v;
     if (int e = gsr_make_view(view_host, &v)) return e;
@@ -576,14 +582,14 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
     if (S > 1) {
         (void)hipMemsetAsync(pairgrad, 0, (size_t)num_pairs * GSR_PAIRGRAD_FLOATS * sizeof(float), (hipStream_t)stream);
         hipLaunchKernelGGL((composite_bwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pairgrad);
+                           tile_order, stream_rec, final_T, dimg, pairgrad);
         hipLaunchKernelGGL((composite_bwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pairgrad);
+                           tile_order, stream_rec, final_T, dimg, pairgrad);
     } else {
         hipLaunchKernelGGL((composite_bwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pairgrad);
+                           tile_order, stream_rec, final_T, dimg, pairgrad);
         hipLaunchKernelGGL((composite_bwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           stream_rec, final_T, dimg, pairgrad);
+                           tile_order, stream_rec, final_T, dimg, pairgrad);
     }
     return gsr_check_launch("composite_bwd");
 }

@@ -5,6 +5,7 @@ produces the image, the visibility mask and the radii; backward produces the gra
 five raw parameter tensors and of ``screen_coords``.  PyTorch only owns the memory and the
 stream; all arithmetic runs in the library.
 """
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -104,7 +105,7 @@ def _check_param(name, t, shape_tail, n=None):
 class RenderState:
     """Everything one forward leaves behind for inspection and for the backward."""
     __slots__ = ("view", "cview", "n", "num_visible", "num_pairs", "mask_u8", "pos2d", "cov2d", "radius_full",
-                 "bbox", "ntiles", "rec", "order", "slot_base", "tile_offsets", "pair_slot", "sorted_gauss",
+                 "bbox", "ntiles", "rec", "order", "slot_base", "tile_offsets", "tile_order", "pair_slot", "sorted_gauss",
                  "stream_rec", "final_T", "img", "pairgrad", "_counters", "_host", "_ready")
 
     def __init__(self):
@@ -213,8 +214,12 @@ def forward_finish(st: RenderState) -> RenderState:
                                  _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream)
     st.img = torch.empty(view.width, view.height, 3, **f32)
     st.final_T = torch.empty(view.width, view.height, **f32)
-    _call("gsr_composite_fwd", lib.gsr_composite_fwd, cv, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.img), _ptr(st.final_T),
-          stream)
+    st.tile_order = None
+    if os.environ.get("GSR_TILE_ORDER", "length") != "id":      # "id": tile-id order (for comparisons)
+        st.tile_order = torch.empty(T, **i32)
+        _call("gsr_tile_order", lib.gsr_tile_order, cv, _ptr(st.tile_offsets), _ptr(st.tile_order), stream)
+    _call("gsr_composite_fwd", lib.gsr_composite_fwd, cv, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.img),
+          _ptr(st.final_T), stream)
     return st
 
 
@@ -238,7 +243,7 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
     pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
-    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.final_T),
+    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T),
                                      _ptr(dimg), I, _ptr(pairgrad), stream)
     st.pairgrad = pairgrad
     if accumulate_into is None:
@@ -268,7 +273,7 @@ def backward_records(st: RenderState, dimg) -> torch.Tensor:
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
     pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
-    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.stream_rec), _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
+    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
     gsum = torch.empty(st.n, 12, **f32)
     _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad),
           _ptr(gsum), stream)

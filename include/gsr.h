@@ -169,18 +169,26 @@ int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, const uint32
                   uint32_t *tile_offsets, uint32_t *pair_slot, uint32_t *sorted_gauss,
                   float *stream_rec, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Order in which the compositing launches take the tiles: tile_order[T] = the tile ids by
+ * descending list length (in 1024 length classes; the order inside a class is unspecified).  Purely a
+ * scheduling aid - the grid of a compositing launch is one to two rounds of resident waves and the
+ * lists of a view differ in length by an order of magnitude, so longest-first shortens the drain;
+ * results do not depend on it. */
+int gsr_tile_order(const gsr_view *view_host, const uint32_t *tile_offsets, uint32_t *tile_order, void *stream);
+
 /* ---- stage 3: compositing -------------------------------------------------------------
  * Replaces Utils/Probability.py:4-23 and GaussianRenderer.py:100-112 for every tile:
  * G = exp(-1/2 d^T Sigma^-1 d) at integer pixel coordinates, alpha = clamp(o*G, 0.01, 0.99),
  * front-to-back blend over the WHOLE list (no early exit, no background).
- * img[W,H,3] and final_T[W,H] are fully overwritten. */
-int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets,
+ * img[W,H,3] and final_T[W,H] are fully overwritten.  tile_order: from gsr_tile_order, or NULL for
+ * tile-id order. */
+int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets, const uint32_t *tile_order,
                       const float *stream_rec, float *img, float *final_T, void *stream);
 
 /* Backward of the blend (autograd of the statements above).  dimg[W,H,3] is dL/dimg.
  * pairgrad[I,12] is fully overwritten; the record of the pair at sorted position p goes to the row
  * named by its stream record's slot field (= pair_slot[p]). */
-int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets,
+int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, const uint32_t *tile_order,
                       const float *stream_rec, const float *final_T, const float *dimg,
                       uint32_t num_pairs, float *pairgrad, void *stream);
 

@@ -56,3 +56,27 @@ def test_sort_pairs_is_a_stable_radix_sort(n, bits, distinct):
     order = np.argsort(masked, kind="stable")
     assert np.array_equal(vo.cpu().numpy()[:n].view(np.uint32), vals[order])
     assert np.array_equal(ko.cpu().numpy()[:n].view(np.uint32), keys[order])
+
+
+@pytest.mark.parametrize("w,h,tile,kind", [(16, 16, 16, "rand"), (1920, 1080, 16, "rand"), (3840, 2160, 16, "rand"),
+                                           (300, 200, 64, "equal"), (640, 480, 16, "empty"), (2000, 1000, 16, "spike")])
+def test_tile_order_is_a_permutation_by_descending_length(w, h, tile, kind):
+    L, lib = _lib()
+    dev = torch.device("cuda:0")
+    T = ((w + tile - 1) // tile) * ((h + tile - 1) // tile)
+    rng = np.random.default_rng(T)
+    lens = {"rand": lambda: rng.integers(0, 2000, size=T), "equal": lambda: np.full(T, 77), "empty": lambda: np.zeros(T, np.int64),
+            "spike": lambda: np.where(rng.random(T) < 0.01, 100000, rng.integers(0, 50, size=T))}[kind]().astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    toff = torch.from_numpy(off.view(np.int32).copy()).to(dev)
+    order = torch.full((T,), -1, dtype=torch.int32, device=dev)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    view = L.make_view(0, 0, w, h, tile, ident, ident, (0.0, 0.0, 0.0))
+    L.check(lib.gsr_tile_order(view, toff.data_ptr(), order.data_ptr(), _stream()), "tile_order")
+    o = order.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(o), np.arange(T)), "not a permutation of the tile ids"
+    got = lens[o]
+    # longest first up to the width of a length class (1/1023 of the longest list, rounded up)
+    slack = int(lens.max()) // 1023 + 1
+    assert (got[:-1] + slack >= got[1:]).all()
+    assert got[0] + slack >= lens.max()

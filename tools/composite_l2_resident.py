@@ -44,8 +44,8 @@ dimg = torch.rand(W, H, 3, device=dev)
 I = 4 * n_list
 pairgrad = torch.empty(I, 12, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-def fwd(): _lib.check(lib.gsr_composite_fwd(view, tile_offsets.data_ptr(), stream.data_ptr(), img.data_ptr(), fT.data_ptr(), s), "fwd")
-def bwd(): _lib.check(lib.gsr_composite_bwd(view, tile_offsets.data_ptr(), stream.data_ptr(), fT.data_ptr(), dimg.data_ptr(), I, pairgrad.data_ptr(), s), "bwd")
+def fwd(): _lib.check(lib.gsr_composite_fwd(view, tile_offsets.data_ptr(), None, stream.data_ptr(), img.data_ptr(), fT.data_ptr(), s), "fwd")
+def bwd(): _lib.check(lib.gsr_composite_bwd(view, tile_offsets.data_ptr(), None, stream.data_ptr(), fT.data_ptr(), dimg.data_ptr(), I, pairgrad.data_ptr(), s), "bwd")
 for name, f in (("fwd", fwd), ("bwd", bwd)):
     f(); torch.cuda.synchronize()
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
