@@ -65,6 +65,11 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
     return true;
 }
 
+// The compositing waves are bound by instruction issue.  When memory-bound kernels of another view
+// run beside them on a second stream (minibatch.render_views), the SIMD's issue arbiter should serve
+// these waves first and give the others the cycles they leave.
+__device__ inline void raise_wave_priority() { __builtin_amdgcn_s_setprio(3); }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // One 64-byte stream record (layout: GSR_STREAM_DWORDS in gsr.h) held in 16 SGPRs.  Values that
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
 {
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
+    raise_wave_priority();
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], cr[2], cg[2], cb[2];   // pixel rows (y0, y0+4): top half, (y0+8, y0+12): bottom half
 #pragma unroll
@@ -478,7 +484,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
 // kTinyT and returns at once in the others; TINY = true does the opposite.  The plain sweep then
 // does not pay (in registers, hence in waves per SIMD) for the rarely needed checked one.
 template <bool TINY, bool ATOMIC>
-__global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                             const uint32_t *__restrict__ tile_order,
                                                             const float *__restrict__ stream_rec,
                                                             const float *__restrict__ final_T,
@@ -488,6 +494,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(ViewK v, const uint3
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
     if (w.begin >= w.end) return;
+    raise_wave_priority();
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], gr[2], gg[2], gb[2];
     bool tiny = false;

@@ -4,7 +4,7 @@ flat fp32 bucket and the buckets are summed with a single all-reduce (RCCL over 
 gloo in the CPU tests).  The reference renders one view per step on one device (``Trainer.py:54-57``);
 this module is what carries that step to N GPUs.
 """
-from typing import List, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -64,3 +64,73 @@ class GradBucket:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         return self
+
+
+_front_streams = {}
+
+
+def _front_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _front_streams:
+        _front_streams[key] = torch.cuda.Stream(device=dev)
+    return _front_streams[key]
+
+
+def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Optional[Callable], grads=None,
+                 accumulate: bool = False, overlap: bool = True, lookahead: int = 2):
+    """Forward + backward of the views of one rank against the same parameters, software-pipelined over
+    two HIP streams.
+
+    A view's work falls into a front part that is bound by memory bandwidth and by the latency of many
+    small launches (stage 1, depth sort, pair emission, tile sort, record stream) and a back part that
+    is bound by the vector ALU (compositing forward and backward, record sums).  The front part of view
+    i+1.. runs on a side stream while the current stream composites view i; ``lookahead`` views are
+    begun before the first one's counters are waited for, so the host never stalls the GPU.
+
+    ``params``: coords, scale_raw, rot_raw, opac_raw, sh.  ``views``: ``ViewSpec``s.
+    ``cotangent(i, state)`` returns dL/dimg of view ``i`` (called with the current stream current, after
+    ``state.img`` is enqueued); ``None`` renders forward only.  The five dense gradients are written to
+    (``accumulate``: added to) ``grads`` by ONE pass over all views.
+    Returns ``(states, grads, g_screens)`` - ``states`` holds every view (``num_visible == 0`` ones have
+    no image), ``g_screens`` one tensor per view that had something visible."""
+    from . import rasterizer as R
+    dev = params[0].device
+    cur = torch.cuda.current_stream(dev)
+    front = _front_stream(dev) if overlap and len(views) > 1 else cur
+    if front is not cur:
+        start = torch.cuda.Event()
+        start.record(cur)
+        front.wait_event(start)          # the parameters may have been written on the current stream
+    begun: List = []
+
+    def begin(i):
+        with torch.cuda.stream(front):
+            begun.append(R.forward_begin(*params, None, views[i]))
+
+    for i in range(min(max(lookahead, 1), len(views))):
+        begin(i)
+    states, live, gsums = [], [], []
+    for i in range(len(views)):
+        st = begun[i]
+        with torch.cuda.stream(front):
+            R.forward_lists(st)
+            if front is not cur:
+                ready = torch.cuda.Event()
+                ready.record(front)
+        if i + lookahead < len(views):
+            begin(i + lookahead)
+        states.append(st)
+        if st.num_visible == 0:
+            continue
+        if front is not cur:
+            cur.wait_event(ready)
+            R.share_with_stream(st, cur)
+        R.forward_composite(st)
+        if cotangent is None:
+            continue
+        live.append(st)
+        gsums.append(R.backward_records(st, cotangent(i, st)))
+    if cotangent is None:
+        return states, None, []
+    grads, g_screens = R.backward_views(live, gsums, *params, grads=grads, accumulate=accumulate)
+    return states, grads, g_screens

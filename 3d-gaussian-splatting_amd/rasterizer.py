@@ -184,11 +184,11 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
     return st
 
 
-def forward_finish(st: RenderState) -> RenderState:
+def forward_lists(st: RenderState) -> RenderState:
     """Waits for the view's counters (the one synchronisation of a render), sizes the per-pair
-    buffers, builds the per-tile lists and composites."""
+    buffers and builds the per-tile lists, the record stream and the tile order."""
     lib = _lib.load()
-    view, cv, n = st.view, st.cview, st.n
+    view, cv = st.view, st.cview
     dev = st.mask_u8.device
     stream = _stream(dev)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -212,15 +212,42 @@ def forward_finish(st: RenderState) -> RenderState:
     _call("gsr_bin_lists", lib.gsr_bin_lists, cv, _ptr(st.order), _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
                                  _ptr(st.tile_offsets), None, _ptr(st.sorted_gauss),
                                  _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream)
-    st.img = torch.empty(view.width, view.height, 3, **f32)
-    st.final_T = torch.empty(view.width, view.height, **f32)
     st.tile_order = None
     if os.environ.get("GSR_TILE_ORDER", "length") != "id":      # "id": tile-id order (for comparisons)
         st.tile_order = torch.empty(T, **i32)
         _call("gsr_tile_order", lib.gsr_tile_order, cv, _ptr(st.tile_offsets), _ptr(st.tile_order), stream)
-    _call("gsr_composite_fwd", lib.gsr_composite_fwd, cv, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.img),
-          _ptr(st.final_T), stream)
     return st
+
+
+def forward_composite(st: RenderState) -> RenderState:
+    """Compositing forward of a view whose lists are built: fills ``st.img`` and ``st.final_T``."""
+    if st.num_visible == 0:
+        return st
+    lib = _lib.load()
+    view = st.view
+    dev = st.mask_u8.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    st.img = torch.empty(view.width, view.height, 3, **f32)
+    st.final_T = torch.empty(view.width, view.height, **f32)
+    _call("gsr_composite_fwd", lib.gsr_composite_fwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec),
+          _ptr(st.img), _ptr(st.final_T), _stream(dev))
+    return st
+
+
+def forward_finish(st: RenderState) -> RenderState:
+    """``forward_lists`` + ``forward_composite`` on the current stream."""
+    return forward_composite(forward_lists(st))
+
+
+def share_with_stream(st: RenderState, stream):
+    """Marks the buffers of a view that were allocated while another stream was current as in use on
+    ``stream`` too, so that the caching allocator does not hand them out again before the work
+    enqueued there has finished."""
+    for name in ("mask_u8", "ntiles", "slot_base", "tile_offsets", "tile_order", "stream_rec", "sorted_gauss", "rec", "bbox",
+                 "order", "pos2d", "cov2d", "radius_full"):
+        t = getattr(st, name)
+        if t is not None:
+            t.record_stream(stream)
 
 
 def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec) -> RenderState:

@@ -26,10 +26,9 @@ sys.path.insert(0, ROOT)
 
 import gsplat_amd  # noqa: E402,F401
 from gsplat_amd.camera import Camera  # noqa: E402
-from gsplat_amd.minibatch import GradBucket, shard_views  # noqa: E402
+from gsplat_amd.minibatch import GradBucket, render_views, shard_views  # noqa: E402
 from gsplat_amd.loss import loss_and_grad  # noqa: E402
-from gsplat_amd.rasterizer import (StageTimer, ViewSpec, backward_records, backward_views, forward_begin,  # noqa: E402
-                                   forward_finish)
+from gsplat_amd.rasterizer import StageTimer, ViewSpec  # noqa: E402
 from gsplat_amd.scenes import synthetic_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
@@ -74,6 +73,8 @@ def main():
     ap.add_argument("--with-loss", action="store_true",
                     help="dL/dimg of each view from the training loss 0.8*L1 + 0.2*(1-SSIM) against a synthetic "
                          "0..255 target (one more kernel per view) instead of a fixed cotangent")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="everything on one stream (kernel durations then are those of kernels running alone)")
     ap.add_argument("--forward-only", action="store_true",
                     help="render only, no backward and no collective (the forward-only stress configuration, e.g. "
                          "--gaussians 6000000 --width 3840 --height 2160)")
@@ -131,28 +132,21 @@ def main():
         params = [model._coords.data, model._scale.data, model._rotation.data, model._opacity.data, model._sh.data]
         opt = Adam(params, lr=1e-3, betas=(0.5, 0.999))      # Trainer.py:15-16,24
 
+    def cotangent(i, st):
+        if targets is not None:    # loss = mean over the minibatch of the per-view training loss
+            return loss_and_grad(st.img, targets[i], 0.2, 1.0 / args.views)[1]
+        return cots[i]
+
     def step():
-        # 1. stage 1 + depth order of every view of the rank, enqueued back to back (no host wait);
-        # 2. per view: lists, compositing forward, compositing backward, per-Gaussian record sums -
-        #    the view's counters reached the host while earlier views were being composited;
-        # 3. ONE pass chains all views to the raw parameters and writes the gradient bucket.
-        begun = [forward_begin(*params, None, view) for view in views]
-        states, gsums = [], []
-        for i, (st, cot) in enumerate(zip(begun, cots)):
-            forward_finish(st)
-            if st.num_visible == 0:
-                continue
-            if i == 0:
-                stats.update(m=st.num_visible, pairs=st.num_pairs)
-            states.append(st)
-            if args.forward_only:
-                continue
-            if targets is not None:    # loss = mean over the minibatch of the per-view training loss
-                _, cot = loss_and_grad(st.img, targets[i], 0.2, 1.0 / args.views)
-            gsums.append(backward_records(st, cot))
+        # The rank's views are software-pipelined over two streams (minibatch.render_views): stage 1,
+        # sorts and lists of the next views run beside the compositing of the current one; ONE pass then
+        # chains all views to the raw parameters and writes the gradient bucket.
+        states, _, g_screens = render_views(params, views, None if args.forward_only else cotangent,
+                                            grads=tuple(grads), overlap=not args.no_overlap)
+        if states and "m" not in stats:
+            stats.update(m=states[0].num_visible, pairs=states[0].num_pairs)
         if args.forward_only:
             return
-        _, g_screens = backward_views(states, gsums, *params, grads=tuple(grads))
         if use_dist and world == 1:
             dist.all_reduce(bucket.flat)      # rehearsal: GradBucket skips the collective for one rank
         else:
@@ -160,7 +154,8 @@ def main():
         if opt is not None:
             # (each rank gathers the statistics of its own views; a trainer sums them over the ranks
             # before it densifies, every 50 iterations)
-            for st, gs in zip(states, g_screens):
+            live = [st for st in states if st.num_visible]
+            for st, gs in zip(live, g_screens):
                 accumulate_stats(model, gs, st.mask_u8)
             opt.step(grads=bucket.views)
 

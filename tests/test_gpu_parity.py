@@ -315,3 +315,49 @@ def test_view_minibatch_backward_equals_the_sum_of_single_views(oracle_mod):
     again, _ = backward_views(states, gsums, *p, grads=tuple(t.clone() for t in grads), accumulate=True)
     for k, a, b in zip(names, again, grads):
         assert_close(a.cpu().numpy(), 2.0 * b.cpu().numpy(), k)
+
+
+def test_render_views_pipelined_over_two_streams_matches_one_stream():
+    """minibatch.render_views overlaps the front part of the next views with the compositing of the
+    current one on a second stream; images, lists and gradients are bit-identical to the one-stream
+    run (twice in a row: buffers handed back to the allocator between the runs must not be reused early),
+    including a view in which nothing is visible."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.camera import Camera
+    from gsplat_amd.minibatch import GradBucket, render_views
+    from gsplat_amd.rasterizer import ViewSpec
+    from gsplat_amd.scenes import synthetic_scene
+    dev = _gpu()
+    sc = synthetic_scene(50_000, 480, 272, 3, 9)
+    p = [t.to(dev) for t in sc.params()]
+    nv = 6
+    gen = torch.Generator().manual_seed(4)
+    cams = []
+    for v in range(nv):
+        ang = 2.0 * np.pi * v / nv
+        pos = np.array([0.2 * np.cos(ang) + (1000.0 if v == 3 else 0.0), 0.2 * np.sin(ang), 0.0])   # view 3 sees nothing
+        cams.append(Camera(pos, np.array([1.0, 0.0, 0.0, 0.0]), sc.fx, sc.fy, sc.width / 2, sc.height / 2, sc.width,
+                           sc.height, device=dev))
+    cots = [torch.rand(sc.width, sc.height, 3, generator=gen).to(dev) for _ in range(nv)]
+    views = [ViewSpec.from_camera(c, 3, 16) for c in cams]
+
+    def run(overlap):
+        bucket = GradBucket(sc.n, dev)
+        states, _, screens = render_views(p, views, lambda i, st: cots[i], grads=bucket.views, overlap=overlap)
+        torch.cuda.synchronize()
+        return ([None if st.img is None else st.img.clone() for st in states], [st.num_pairs for st in states],
+                bucket.flat.clone(), [s.clone() for s in screens])
+
+    ref = run(False)
+    assert ref[0][3] is None and sum(im is not None for im in ref[0]) == nv - 1
+    for _ in range(2):
+        got = run(True)
+        assert got[1] == ref[1]
+        for a, b in zip(got[0], ref[0]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)
+        assert torch.equal(got[2], ref[2])
+        assert len(got[3]) == len(ref[3]) and all(torch.equal(a, b) for a, b in zip(got[3], ref[3]))
+    fwd_only, none_grads, no_screens = render_views(p, views, None)
+    assert none_grads is None and no_screens == [] and torch.equal(fwd_only[0].img, ref[0][0])
