@@ -21,7 +21,10 @@ __global__ void iota_kernel(uint32_t *__restrict__ out, uint32_t n)
 // contiguous range, which the wave writes 64 slots at a time - lane j owns slot start + 64 k + j and
 // finds the Gaussian it belongs to with a binary search over the 64 slot bases (held one per lane).
 // All global writes are fully coalesced; one thread per Gaussian writing its own slots is not.
+// slot_seq (may be null): the slot bases in depth order with the total at [n] - read in place of the
+// two per-Gaussian gathers of slot_base and ntiles.
 __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t *__restrict__ order,
+                                                         const uint32_t *__restrict__ slot_seq,
                                                          const uint32_t *__restrict__ slot_base,
                                                          const int32_t *__restrict__ bbox,
                                                          const uint32_t *__restrict__ ntiles,
@@ -33,8 +36,13 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
     int x0 = 0, y0 = 0, ny = 1;
     if (s < v.n) {
         g = order[s];
-        nt = ntiles[g];
-        sb = slot_base[g];
+        if (slot_seq) {
+            sb = slot_seq[s];
+            nt = slot_seq[s + 1] - sb;
+        } else {
+            nt = ntiles[g];
+            sb = slot_base[g];
+        }
         if (nt) {
             const int4 bb = reinterpret_cast<const int4 *>(bbox)[g];
             int x1, y1;
@@ -251,7 +259,7 @@ extern "C" size_t gsr_bin_offsets_workspace_bytes(uint32_t n)
 }
 
 extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uint32_t *order,
-                               uint32_t *slot_base, gsr_counters *counters, void *workspace,
+                               uint32_t *slot_base, uint32_t *slot_seq, gsr_counters *counters, void *workspace,
                                size_t workspace_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -262,6 +270,7 @@ extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint
     if (!counters) { gsr_set_error("gsr_bin_offsets: null counters"); return GSR_ERR_ARG; }
     if (n == 0) {
         (void)hipMemsetAsync(&counters->num_pairs, 0, sizeof(uint32_t), st);
+        if (slot_seq) (void)hipMemsetAsync(slot_seq, 0, sizeof(uint32_t), st);
         return GSR_OK;
     }
     if (!depth_key || !ntiles || !order || !slot_base) { gsr_set_error("gsr_bin_offsets: null pointer"); return GSR_ERR_ARG; }
@@ -281,7 +290,8 @@ extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint
         return e;
     if (!in_first) { gsr_set_error("gsr_bin_offsets: unexpected number of sort passes"); return GSR_ERR_LAUNCH; }
     // slot_base[order[s]] = sum over s' < s of ntiles[order[s']]
-    if (int e = gsr_exclusive_scan_along(ntiles, order, slot_base, n, &counters->num_pairs, scan_ws, scan_bytes, stream))
+    if (int e = gsr_exclusive_scan_along(ntiles, order, slot_base, n, &counters->num_pairs, scan_ws, scan_bytes, stream,
+                                         slot_seq))
         return e;
     return gsr_check_launch("bin_offsets");
 }
@@ -293,7 +303,7 @@ extern "C" size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs)
 }
 
 extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, const uint32_t *slot_base,
-                             const int32_t *bbox, const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
+                             const uint32_t *slot_seq, const int32_t *bbox, const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
                              uint32_t *tile_offsets, uint32_t *pair_slot, uint32_t *sorted_gauss,
                              float *stream_rec, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -325,8 +335,8 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, c
     uint64_t *sorted_owner_slot = (uint64_t *)(ws + 4 * arr);
     void *sort_ws = ws + 6 * arr;
     const size_t sort_bytes = workspace_bytes - 6 * arr;
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, order, slot_base, bbox,
-                       ntiles, tile_key, owner_slot, num_pairs);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, order, slot_seq, slot_base,
+                       bbox, ntiles, tile_key, owner_slot, num_pairs);
     bool in_first;
     if (int e = gsr_sort_pingpong64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0,
                                     bits_for((uint32_t)v.T), sort_ws, sort_bytes, stream, &in_first))

@@ -344,17 +344,33 @@ __device__ inline void add_record(double (&acc)[9], const float *__restrict__ pa
     acc[8] += ((double)c.x + (double)c.y) + ((double)c.z + (double)c.w);   // blue arrives as four partial sums
 }
 
+// ORDERED: thread s takes the Gaussian at position s of the depth order, order[s], whose records are
+// the slots slot_seq[s] .. slot_seq[s+1]: neighbouring threads then read neighbouring records (slots
+// follow the depth order), where in index order every thread reads from a place of its own and the
+// lines it touches are fetched half empty.  Otherwise thread i takes Gaussian i.
+template <bool ORDERED>
 __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, const uint8_t *__restrict__ mask,
                                                           const uint32_t *__restrict__ slot_base,
                                                           const uint32_t *__restrict__ ntiles,
+                                                          const uint32_t *__restrict__ order,
+                                                          const uint32_t *__restrict__ slot_seq,
                                                           const float *__restrict__ pairgrad,
                                                           float *__restrict__ gsum)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool live = i < n && mask[i];
-    const uint32_t nt = live ? ntiles[i] : 0u;
-    const uint32_t e0 = live ? slot_base[i] : 0u;
+    uint32_t nt = 0u, e0 = 0u, row = (uint32_t)i;
+    if (ORDERED) {
+        if (i < n) {
+            row = order[i];
+            e0 = slot_seq[i];
+            nt = slot_seq[i + 1] - e0;   // a culled Gaussian has no tiles
+        }
+    } else {
+        const bool live = i < n && mask[i];
+        nt = live ? ntiles[i] : 0u;
+        e0 = live ? slot_base[i] : 0u;
+    }
     double acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, const uint8_t *
         }
     }
     if (i < n) {
-        float4 *dst = reinterpret_cast<float4 *>(gsum + (size_t)i * 12);
+        float4 *dst = reinterpret_cast<float4 *>(gsum + (size_t)row * 12);
         dst[0] = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
         dst[1] = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
         dst[2] = make_float4((float)acc[8], 0.f, 0.f, 0.f);
@@ -665,12 +681,17 @@ extern "C" size_t gsr_preprocess_bwd_workspace_bytes(uint32_t n)
 }
 
 extern "C" int gsr_pair_reduce(uint32_t n, const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
+                               const uint32_t *order, const uint32_t *slot_seq,
                                const float *pairgrad, float *gsum, void *stream)
 {
     if (n == 0) return GSR_OK;
     if (!mask || !slot_base || !ntiles || !gsum) { gsr_set_error("gsr_pair_reduce: null pointer"); return GSR_ERR_ARG; }
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3(gsr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, (int)n, mask,
-                       slot_base, ntiles, pairgrad, gsum);
+    if (order && slot_seq)
+        hipLaunchKernelGGL(pair_reduce_kernel<true>, dim3(gsr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, (int)n,
+                           mask, slot_base, ntiles, order, slot_seq, pairgrad, gsum);
+    else
+        hipLaunchKernelGGL(pair_reduce_kernel<false>, dim3(gsr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, (int)n,
+                           mask, slot_base, ntiles, order, slot_seq, pairgrad, gsum);
     return gsr_check_launch("pair_reduce");
 }
 
@@ -742,7 +763,7 @@ extern "C" int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords
     }
     if (v.n == 0) return GSR_OK;
     float *gsum = (float *)workspace;
-    if (int e = gsr_pair_reduce((uint32_t)v.n, mask, slot_base, ntiles, pairgrad, gsum, stream)) return e;
+    if (int e = gsr_pair_reduce((uint32_t)v.n, mask, slot_base, ntiles, nullptr, nullptr, pairgrad, gsum, stream)) return e;
     const float *gsum_c = gsum;
     return gsr_preprocess_bwd_views(view_host, 1, coords, scale_raw, rot_raw, opac_raw, sh, &mask, &gsum_c, g_coords,
                                     g_scale, g_rot, g_opac, g_sh, &g_screen, accumulate, stream);

@@ -81,9 +81,12 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ 
     if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
+// out_seq (may be null): the same prefix sums in SEQUENCE order, out_seq[i] for i < n and the total at
+// out_seq[n]
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t *in, const uint32_t *__restrict__ idx,
                                                                   uint32_t *out, uint32_t n,
-                                                                  const uint32_t *__restrict__ block_sums)
+                                                                  const uint32_t *__restrict__ block_sums,
+                                                                  uint32_t *__restrict__ out_seq)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -99,7 +102,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
     uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan(s, lds, total);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) out[at[k]] = run;
+        if (base + k < n) {
+            out[at[k]] = run;
+            if (out_seq) {
+                out_seq[base + k] = run;
+                if (base + k == n - 1) out_seq[n] = run + v[k];
+            }
+        }
         run += v[k];
     }
 }
@@ -282,7 +291,7 @@ extern "C" size_t gsr_scan_workspace_bytes(uint32_t n)
 
 // library-internal: out[idx[i]] = sum over j < i of in[idx[j]]  (idx == null: the plain scan)
 int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
-                             void *workspace, size_t workspace_bytes, void *stream)
+                             void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq)
 {
     hipStream_t st = (hipStream_t)stream;
     if (workspace_bytes < gsr_scan_workspace_bytes(n) || !workspace) {
@@ -292,6 +301,7 @@ int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *
     }
     if (n == 0) {
         if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), st);
+        if (out_seq) (void)hipMemsetAsync(out_seq, 0, sizeof(uint32_t), st);
         return GSR_OK;
     }
     if (!in || !out) { gsr_set_error("gsr_exclusive_scan: null pointer"); return GSR_ERR_ARG; }
@@ -299,14 +309,14 @@ int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *
     const uint32_t nb = gsr_div_up(n, SCAN_TILE);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb, total);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, out, n, sums);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, out, n, sums, out_seq);
     return gsr_check_launch("exclusive_scan");
 }
 
 extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
-    return gsr_exclusive_scan_along(in, nullptr, out, n, total, workspace, workspace_bytes, stream);
+    return gsr_exclusive_scan_along(in, nullptr, out, n, total, workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)

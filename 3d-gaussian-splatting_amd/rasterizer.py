@@ -105,7 +105,7 @@ def _check_param(name, t, shape_tail, n=None):
 class RenderState:
     """Everything one forward leaves behind for inspection and for the backward."""
     __slots__ = ("view", "cview", "n", "num_visible", "num_pairs", "mask_u8", "pos2d", "cov2d", "radius_full",
-                 "bbox", "ntiles", "rec", "order", "slot_base", "tile_offsets", "tile_order", "pair_slot", "sorted_gauss",
+                 "bbox", "ntiles", "rec", "order", "slot_base", "slot_seq", "tile_offsets", "tile_order", "pair_slot", "sorted_gauss",
                  "stream_rec", "final_T", "img", "pairgrad", "_counters", "_host", "_ready")
 
     def __init__(self):
@@ -164,10 +164,11 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
                                       _ptr(st.rec), _ptr(counters), stream)
     st.order = torch.empty(n, **i32)
     st.slot_base = torch.empty(n, **i32)
+    st.slot_seq = torch.empty(n + 1, **i32)
     ws_bytes = int(lib.gsr_bin_offsets_workspace_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _call("gsr_bin_offsets", lib.gsr_bin_offsets, _ptr(depth_key), _ptr(st.ntiles), n, _ptr(st.order), _ptr(st.slot_base),
-                                   _ptr(counters), _ptr(ws), ws_bytes, stream)
+                                   _ptr(st.slot_seq), _ptr(counters), _ptr(ws), ws_bytes, stream)
     # read the counters back on a side stream: the copy is ordered after bin_offsets only, not after
     # whatever the caller enqueues on the main stream next
     main = torch.cuda.current_stream(dev)
@@ -209,7 +210,7 @@ def forward_lists(st: RenderState) -> RenderState:
     st.stream_rec = torch.empty(max(I, 1), _lib.STREAM_DWORDS, **f32)
     ws_bytes = int(lib.gsr_bin_lists_workspace_bytes(I))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _call("gsr_bin_lists", lib.gsr_bin_lists, cv, _ptr(st.order), _ptr(st.slot_base), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
+    _call("gsr_bin_lists", lib.gsr_bin_lists, cv, _ptr(st.order), _ptr(st.slot_base), _ptr(st.slot_seq), _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), I,
                                  _ptr(st.tile_offsets), None, _ptr(st.sorted_gauss),
                                  _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream)
     st.tile_order = None
@@ -243,7 +244,7 @@ def share_with_stream(st: RenderState, stream):
     """Marks the buffers of a view that were allocated while another stream was current as in use on
     ``stream`` too, so that the caching allocator does not hand them out again before the work
     enqueued there has finished."""
-    for name in ("mask_u8", "ntiles", "slot_base", "tile_offsets", "tile_order", "stream_rec", "sorted_gauss", "rec", "bbox",
+    for name in ("mask_u8", "ntiles", "slot_base", "slot_seq", "tile_offsets", "tile_order", "stream_rec", "sorted_gauss", "rec", "bbox",
                  "order", "pos2d", "cov2d", "radius_full"):
         t = getattr(st, name)
         if t is not None:
@@ -302,7 +303,8 @@ def backward_records(st: RenderState, dimg) -> torch.Tensor:
     pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
     _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
     gsum = torch.empty(st.n, 12, **f32)
-    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad),
+    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), None, None,   # (index order: measured faster than depth order)
+          _ptr(pairgrad),
           _ptr(gsum), stream)
     return gsum
 

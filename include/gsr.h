@@ -112,11 +112,14 @@ int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const flo
  * num_views views (host arrays of per-view device pointers) to the raw parameters in one pass: the
  * dense gradients are written (accumulate == 0) or added to (accumulate != 0) ONCE for all views,
  * where per-view calls of gsr_preprocess_bwd re-read and re-write them for every view.
+ * gsr_pair_reduce's order and slot_seq (both from gsr_bin_offsets; both may be NULL) let it walk the
+ * Gaussians in depth order, in which their records are consecutive in memory; the sums are the same.
  * g_screen_host[v][N,3] receives view v's screen_coords gradient.  All views must share n and
  * sh_degree.  At most GSR_MAX_VIEWS views go into one kernel launch; more are processed in groups. */
 #define GSR_MAX_VIEWS 8
 int gsr_pair_reduce(uint32_t n, const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
-                    const float *pairgrad, float *gsum, void *stream);
+                    const uint32_t *order, const uint32_t *slot_seq, const float *pairgrad, float *gsum,
+                    void *stream);
 int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num_views, const float *coords,
                              const float *scale_raw, const float *rot_raw, const float *opac_raw,
                              const float *sh, const uint8_t *const *mask_host, const float *const *gsum_host,
@@ -150,14 +153,16 @@ int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *
  * order[N]: Gaussian indices by (depth_key, index) ascending - visible ones first;
  * slot_base[N] (N-indexed): first emission slot of each Gaussian; slots follow depth order, so
  * slot_base[order[s]] is the exclusive scan of ntiles[order[s]]; counters->num_pairs = total.
+ * slot_seq[N+1] (may be NULL): the same slot bases in depth order, slot_seq[s] = slot_base[order[s]],
+ * with the total at slot_seq[N] - consumers that walk the depth order read it instead of gathering.
  * depth_key is clobbered.  workspace: gsr_bin_offsets_workspace_bytes(n). */
 size_t gsr_bin_offsets_workspace_bytes(uint32_t n);
 int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uint32_t *order,
-                    uint32_t *slot_base, gsr_counters *counters, void *workspace,
+                    uint32_t *slot_base, uint32_t *slot_seq, gsr_counters *counters, void *workspace,
                     size_t workspace_bytes, void *stream);
 
-/* Per-tile lists.  order and slot_base come from gsr_bin_offsets; num_pairs must be the value read
- * back from counters->num_pairs.
+/* Per-tile lists.  order, slot_base and slot_seq (may be NULL) come from gsr_bin_offsets; num_pairs
+ * must be the value read back from counters->num_pairs.
  * Outputs: tile_offsets[T+1] u32 (tile id = yi + n_block_h * xi, Utils/Screen.py:38-39),
  * pair_slot[I] (emission slot of the pair at each sorted position; may be NULL), sorted_gauss[I] (Gaussian
  * index at each sorted position - the concatenated per-tile depth-ordered lists),
@@ -165,7 +170,7 @@ int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uin
  * num_pairs * 64 must stay below 2^32 (the kernels address the stream with 32-bit byte offsets).  workspace: gsr_bin_lists_workspace_bytes(num_pairs). */
 size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs);
 int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, const uint32_t *slot_base,
-                  const int32_t *bbox, const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
+                  const uint32_t *slot_seq, const int32_t *bbox, const uint32_t *ntiles, const float *rec, uint32_t num_pairs,
                   uint32_t *tile_offsets, uint32_t *pair_slot, uint32_t *sorted_gauss,
                   float *stream_rec, void *workspace, size_t workspace_bytes, void *stream);
 
