@@ -21,7 +21,7 @@ ADAM_MAX_TENSORS = 8
 # Every symbol include/gsr.h declares.
 SYMBOLS = (
     "gsr_last_error", "gsr_version", "gsr_preprocess_fwd", "gsr_preprocess_bwd", "gsr_preprocess_bwd_workspace_bytes",
-    "gsr_pair_reduce", "gsr_preprocess_bwd_views",
+    "gsr_pair_reduce", "gsr_preprocess_bwd_views", "gsr_sh_grad_views",
     "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_sort_pairs64", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
     "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order",
     "gsr_composite_fwd", "gsr_composite_bwd",
@@ -88,7 +88,8 @@ def load():
     lib.gsr_preprocess_bwd.argtypes = [C.POINTER(GsrView)] + [vp] * 15 + [C.c_int, vp, C.c_size_t, vp]
     lib.gsr_pair_reduce.argtypes = [C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd_views.argtypes = ([C.POINTER(GsrView), C.c_uint32] + [vp] * 5 + [C.POINTER(vp)] * 2 + [vp] * 5 +
-                                             [C.POINTER(vp), C.c_int, vp])
+                                             [C.POINTER(vp), C.POINTER(vp), C.c_int, vp])
+    lib.gsr_sh_grad_views.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, C.POINTER(vp), vp, C.c_int, vp]
     lib.gsr_sort_pairs.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
     lib.gsr_sort_pairs64.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
     lib.gsr_exclusive_scan.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_size_t, vp]

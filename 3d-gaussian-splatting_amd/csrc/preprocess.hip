@@ -415,6 +415,7 @@ struct BwdViews {
     const uint8_t *mask[kMaxViews];   // visibility of the view
     const float *gsum[kMaxViews];     // summed gradient records of the view, [N,12]
     float *g_screen[kMaxViews];       // gradient of the view's screen_coords leaf, [N,3]
+    float *g_color[kMaxViews];        // (may be null) dL/d(colour) of the view as it reaches the clamp, [N,3]
 };
 
 // Backward of stage 1 for up to kMaxViews views of ONE parameter set: the gradients of all views are
@@ -433,6 +434,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     if (i >= n) return;
     float gc[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, gr[4] = {0.f, 0.f, 0.f, 0.f};
     float go = 0.f;
+    // g_sh == null: the sh gradient is left to gsr_sh_grad_views (it is a sum over the views of outer
+    // products basis x dL/d(colour), which ranks that share the parameters can rebuild from the 3 colour
+    // gradients per view instead of exchanging 48 floats)
+    const bool write_sh = g_sh != nullptr;
     float4 *dsh = reinterpret_cast<float4 *>(g_sh + (size_t)i * 48);
 
     bool any = false;
@@ -441,8 +446,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         for (int vv = 0; vv < a.nv; ++vv) {
             float *gsv = a.g_screen[vv] + 3 * (size_t)i;
             gsv[0] = 0.0f; gsv[1] = 0.0f; gsv[2] = 0.0f;
+            if (a.g_color[vv]) {
+                float *gcv = a.g_color[vv] + 3 * (size_t)i;
+                gcv[0] = 0.0f; gcv[1] = 0.0f; gcv[2] = 0.0f;
+            }
         }
-        if (!ACC) {
+        if (!ACC && write_sh) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) dsh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -560,8 +569,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
                 for (int vv = 0; vv < a.nv; ++vv) {
-                    if (!a.mask[vv][i]) continue;
+                    if (!a.mask[vv][i]) {
+                        if (a.g_color[vv]) a.g_color[vv][3 * (size_t)i + ch] = 0.0f;
+                        continue;
+                    }
                     const float d_col = a.gsum[vv][(size_t)i * 12 + 6 + ch];
+                    if (a.g_color[vv]) a.g_color[vv][3 * (size_t)i + ch] = d_col;
                     const float dx = p[0] - a.cam[vv].cam[0], dy = p[1] - a.cam[vv].cam[1], dz = p[2] - a.cam[vv].cam[2];
                     float bs[16];
                     sh_basis(deg, dx, dy, dz, bs);
@@ -583,6 +596,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 }
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
+                    if (!write_sh) break;
                     float4 o4 = make_float4(acc[4 * v4], acc[4 * v4 + 1], acc[4 * v4 + 2], acc[4 * v4 + 3]);
                     if (ACC) {
                         if (4 * v4 < K) {
@@ -653,6 +667,71 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     put<ACC>(g_opac + i, go);
 }
 
+// The sh gradient of a view minibatch from the per-view colour gradients: for every Gaussian and
+// channel, sum over the views of dL/d(colour) * basis(direction of the view), where the colour passes
+// its clamp (GaussianRenderer.py:71-74).  Same arithmetic and the same order over the views as the sh
+// part of preprocess_bwd_kernel, so the result does not depend on how the views were spread over
+// ranks.  A view in which the Gaussian is culled carries a zero colour gradient and is skipped.
+struct ShViews {
+    int nv;
+    float cam[kMaxViews][3];
+    const float *g_color[kMaxViews];   // [N,3] per view
+};
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void sh_grad_views_kernel(ShViews a, int n, int deg, int K,
+                                                            const float *__restrict__ coords,
+                                                            const float *__restrict__ sh, float *__restrict__ g_sh)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
+    const float4 *src = reinterpret_cast<const float4 *>(sh + (size_t)i * 48);
+    float4 *dsh = reinterpret_cast<float4 *>(g_sh + (size_t)i * 48);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float co[16], acc[16];
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v4 * 4 < K) t = src[ch * 4 + v4];
+            co[v4 * 4 + 0] = t.x; co[v4 * 4 + 1] = t.y; co[v4 * 4 + 2] = t.z; co[v4 * 4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+        for (int vv = 0; vv < a.nv; ++vv) {
+            const float d_col = a.g_color[vv][3 * (size_t)i + ch];
+            if (d_col == 0.0f) continue;
+            const float dx = p[0] - a.cam[vv][0], dy = p[1] - a.cam[vv][1], dz = p[2] - a.cam[vv][2];
+            float bs[16];
+            sh_basis(deg, dx, dy, dz, bs);
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < K) t += bs[k] * co[k];
+            t += 0.5f;
+            if (t >= 0.0f) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < K) acc[k] += d_col * bs[k];
+            }
+        }
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            float4 o4 = make_float4(acc[4 * v4], acc[4 * v4 + 1], acc[4 * v4 + 2], acc[4 * v4 + 3]);
+            if (ACC) {
+                if (4 * v4 < K) {
+                    const float4 t = dsh[ch * 4 + v4];
+                    o4.x += t.x; o4.y += t.y; o4.z += t.z; o4.w += t.w;
+                    dsh[ch * 4 + v4] = o4;
+                }
+            } else {
+                dsh[ch * 4 + v4] = o4;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
@@ -699,14 +778,19 @@ extern "C" int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num
                                         const float *scale_raw, const float *rot_raw, const float *opac_raw,
                                         const float *sh, const uint8_t *const *mask_host, const float *const *gsum_host,
                                         float *g_coords, float *g_scale, float *g_rot, float *g_opac, float *g_sh,
-                                        float *const *g_screen_host, int accumulate, void *stream)
+                                        float *const *g_screen_host, float *const *g_color_host, int accumulate,
+                                        void *stream)
 {
     if (num_views == 0 || !views_host || !mask_host || !gsum_host || !g_screen_host) {
         gsr_set_error("gsr_preprocess_bwd_views: no views or null view arrays");
         return GSR_ERR_ARG;
     }
-    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !g_coords || !g_scale || !g_rot || !g_opac || !g_sh) {
+    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !g_coords || !g_scale || !g_rot || !g_opac) {
         gsr_set_error("gsr_preprocess_bwd_views: null pointer");
+        return GSR_ERR_ARG;
+    }
+    if (!g_sh && !g_color_host) {
+        gsr_set_error("gsr_preprocess_bwd_views: g_sh may only be left out when the colour gradients are asked for");
         return GSR_ERR_ARG;
     }
     ViewK first;
@@ -724,7 +808,7 @@ extern "C" int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num
                 gsr_set_error("gsr_preprocess_bwd_views: view %u differs from view 0 in n or sh_degree", v0 + k);
                 return GSR_ERR_ARG;
             }
-            if (!mask_host[v0 + k] || !gsum_host[v0 + k] || !g_screen_host[v0 + k]) {
+            if (!mask_host[v0 + k] || !gsum_host[v0 + k] || !g_screen_host[v0 + k] || (g_color_host && !g_color_host[v0 + k])) {
                 gsr_set_error("gsr_preprocess_bwd_views: null pointer for view %u", v0 + k);
                 return GSR_ERR_ARG;
             }
@@ -735,8 +819,9 @@ extern "C" int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num
             a.mask[k] = mask_host[v0 + k];
             a.gsum[k] = gsum_host[v0 + k];
             a.g_screen[k] = g_screen_host[v0 + k];
+            a.g_color[k] = g_color_host ? g_color_host[v0 + k] : nullptr;
         }
-        for (int k = a.nv; k < kMaxViews; ++k) { a.mask[k] = nullptr; a.gsum[k] = nullptr; a.g_screen[k] = nullptr; }
+        for (int k = a.nv; k < kMaxViews; ++k) { a.mask[k] = nullptr; a.gsum[k] = nullptr; a.g_screen[k] = nullptr; a.g_color[k] = nullptr; }
         if (accumulate || v0 > 0)
             hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a, first.n, first.deg,
                                first.K, coords, scale_raw, rot_raw, opac_raw, sh, g_coords, g_scale, g_rot, g_opac, g_sh);
@@ -766,5 +851,42 @@ extern "C" int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords
     if (int e = gsr_pair_reduce((uint32_t)v.n, mask, slot_base, ntiles, nullptr, nullptr, pairgrad, gsum, stream)) return e;
     const float *gsum_c = gsum;
     return gsr_preprocess_bwd_views(view_host, 1, coords, scale_raw, rot_raw, opac_raw, sh, &mask, &gsum_c, g_coords,
-                                    g_scale, g_rot, g_opac, g_sh, &g_screen, accumulate, stream);
+                                    g_scale, g_rot, g_opac, g_sh, &g_screen, nullptr, accumulate, stream);
+}
+
+extern "C" int gsr_sh_grad_views(const gsr_view *views_host, uint32_t num_views, const float *coords, const float *sh,
+                                 const float *const *g_color_host, float *g_sh, int accumulate, void *stream)
+{
+    if (num_views == 0 || !views_host || !g_color_host) {
+        gsr_set_error("gsr_sh_grad_views: no views or null view arrays");
+        return GSR_ERR_ARG;
+    }
+    if (!coords || !sh || !g_sh) { gsr_set_error("gsr_sh_grad_views: null pointer"); return GSR_ERR_ARG; }
+    ViewK first;
+    if (int e = gsr_make_view(&views_host[0], &first)) return e;
+    if (first.n == 0) return GSR_OK;
+    const dim3 grid(gsr_div_up(first.n, 256)), block(256);
+    for (uint32_t v0 = 0; v0 < num_views; v0 += kMaxViews) {
+        ShViews a;
+        a.nv = (int)(num_views - v0 < (uint32_t)kMaxViews ? num_views - v0 : (uint32_t)kMaxViews);
+        for (int k = 0; k < kMaxViews; ++k) { a.g_color[k] = nullptr; a.cam[k][0] = a.cam[k][1] = a.cam[k][2] = 0.0f; }
+        for (int k = 0; k < a.nv; ++k) {
+            ViewK v;
+            if (int e = gsr_make_view(&views_host[v0 + k], &v)) return e;
+            if (v.n != first.n || v.deg != first.deg) {
+                gsr_set_error("gsr_sh_grad_views: view %u differs from view 0 in n or sh_degree", v0 + k);
+                return GSR_ERR_ARG;
+            }
+            if (!g_color_host[v0 + k]) { gsr_set_error("gsr_sh_grad_views: null pointer for view %u", v0 + k); return GSR_ERR_ARG; }
+            for (int j = 0; j < 3; ++j) a.cam[k][j] = v.cam[j];
+            a.g_color[k] = g_color_host[v0 + k];
+        }
+        if (accumulate || v0 > 0)
+            hipLaunchKernelGGL(sh_grad_views_kernel<true>, grid, block, 0, (hipStream_t)stream, a, first.n, first.deg, first.K,
+                               coords, sh, g_sh);
+        else
+            hipLaunchKernelGGL(sh_grad_views_kernel<false>, grid, block, 0, (hipStream_t)stream, a, first.n, first.deg, first.K,
+                               coords, sh, g_sh);
+    }
+    return gsr_check_launch("sh_grad_views");
 }

@@ -77,7 +77,7 @@ def _front_stream(dev):
 
 
 def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Optional[Callable], grads=None,
-                 accumulate: bool = False, overlap: bool = True, lookahead: int = 2):
+                 accumulate: bool = False, overlap: bool = True, lookahead: int = 2, g_colors=None):
     """Forward + backward of the views of one rank against the same parameters, software-pipelined over
     two HIP streams.
 
@@ -90,7 +90,9 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     ``params``: coords, scale_raw, rot_raw, opac_raw, sh.  ``views``: ``ViewSpec``s.
     ``cotangent(i, state)`` returns dL/dimg of view ``i`` (called with the current stream current, after
     ``state.img`` is enqueued); ``None`` renders forward only.  The five dense gradients are written to
-    (``accumulate``: added to) ``grads`` by ONE pass over all views.
+    (``accumulate``: added to) ``grads`` by ONE pass over all views.  ``g_colors`` (a ``[len(views),N,3]``
+    tensor): the sh gradient is left out and the colour gradient of every view is stored there instead,
+    for ``reduce_gradients``.
     Returns ``(states, grads, g_screens)`` - ``states`` holds every view (``num_visible == 0`` ones have
     no image), ``g_screens`` one tensor per view that had something visible."""
     from . import rasterizer as R
@@ -132,5 +134,48 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
         gsums.append(R.backward_records(st, cotangent(i, st)))
     if cotangent is None:
         return states, None, []
-    grads, g_screens = R.backward_views(live, gsums, *params, grads=grads, accumulate=accumulate)
+    cols = None
+    if g_colors is not None:
+        cols = [g_colors[i] for i, st in enumerate(states) if st.num_visible]
+        for i, st in enumerate(states):
+            if not st.num_visible:
+                g_colors[i].zero_()
+    grads, g_screens = R.backward_views(live, gsums, *params, grads=grads, accumulate=accumulate, g_colors=cols)
     return states, grads, g_screens
+
+
+SMALL_FLOATS = sum(FIELD_SIZES[:4])     # coords, scale, rotation, opacity: what is summed over the ranks
+
+
+def can_factor(n_views: int, world_size: int) -> bool:
+    """The factored exchange gathers equal blocks of views from the ranks."""
+    return world_size >= 1 and n_views % world_size == 0
+
+
+def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: int, rebuild_sh: Callable, group=None,
+                     force_collectives: bool = False):
+    """Gradient exchange of one step between ranks that hold the same parameters, without moving the
+    sh gradient: the 11 floats per Gaussian of coords / scale / rotation / opacity are summed with one
+    all-reduce, the colour gradients of the rank's views (``g_colors_local`` ``[V/world, N, 3]``, from
+    ``render_views(..., g_colors=...)``) are gathered from all ranks into ``[V, N, 3]`` (rank r holds the
+    views ``shard_views(V, world, r)``), and ``rebuild_sh(g_colors_all)`` writes ``bucket.sh`` from them
+    (``rasterizer.sh_grad_views``).  Per rank that is 11 N floats reduced and 3 N floats per view
+    gathered in place of 59 N floats reduced; the sh gradient comes out identical on every rank and
+    identical to a single-rank run.  ``force_collectives`` issues the two collectives for a single
+    rank too (a rehearsal of the multi-rank path).  Returns the gathered colour gradients."""
+    import torch.distributed as dist
+    n = bucket.n
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if not can_factor(n_views, world):
+        raise ValueError(f"{n_views} views do not split evenly over {world} ranks")
+    per_rank = n_views // world
+    if tuple(g_colors_local.shape) != (per_rank, n, 3) or not g_colors_local.is_contiguous():
+        raise ValueError(f"g_colors_local has shape {tuple(g_colors_local.shape)}, expected a contiguous [{per_rank},{n},3]")
+    if world == 1 and not (force_collectives and dist.is_available() and dist.is_initialized()):
+        g_all = g_colors_local
+    else:
+        dist.all_reduce(bucket.flat[:n * SMALL_FLOATS], op=dist.ReduceOp.SUM, group=group)
+        g_all = torch.empty((n_views, n, 3), dtype=g_colors_local.dtype, device=g_colors_local.device)
+        dist.all_gather_into_tensor(g_all, g_colors_local, group=group)
+    rebuild_sh(g_all)
+    return g_all

@@ -309,10 +309,14 @@ def backward_records(st: RenderState, dimg) -> torch.Tensor:
     return gsum
 
 
-def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grads=None, accumulate=False):
+def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grads=None, accumulate=False, g_colors=None):
     """Second half for a whole view minibatch: chains the per-Gaussian sums of all views to the raw
     parameters and writes (or, with ``accumulate``, adds to) the five dense gradients ONCE.
-    ``states``/``gsums``: the views that had something visible.  Returns (grads, [g_screen per view])."""
+    ``states``/``gsums``: the views that had something visible.  Returns (grads, [g_screen per view]).
+
+    ``g_colors`` (one ``[N,3]`` tensor per state): the sh gradient is NOT written; instead every view's
+    colour gradient is stored there, for ranks that rebuild the sh gradient of the whole minibatch
+    with ``sh_grad_views`` after gathering them (``minibatch.reduce_gradients``)."""
     import ctypes as C
     lib = _lib.load()
     dev = coords.device
@@ -324,7 +328,7 @@ def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grad
     nv = len(states)
     if nv == 0:
         if not accumulate:
-            for g in grads:
+            for g in (grads[:4] if g_colors is not None else grads):
                 g.zero_()
         return grads, []
     g_screens = [torch.empty(n, 3, **f32) for _ in range(nv)]
@@ -333,12 +337,38 @@ def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grad
     masks = (vp * nv)(*[_ptr(st.mask_u8) for st in states])
     sums = (vp * nv)(*[_ptr(g) for g in gsums])
     screens = (vp * nv)(*[_ptr(g) for g in g_screens])
+    colors = None
+    if g_colors is not None:
+        if len(g_colors) != nv:
+            raise ValueError(f"{len(g_colors)} colour-gradient buffers for {nv} views")
+        for g in g_colors:
+            if tuple(g.shape) != (n, 3) or g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev:
+                raise ValueError("a colour-gradient buffer must be a contiguous float32 [N,3] tensor on the parameters' device")
+        colors = (vp * nv)(*[_ptr(g) for g in g_colors])
     if opac_raw.dim() == 1:
         opac_raw = opac_raw.unsqueeze(1)
     _call("gsr_preprocess_bwd_views", lib.gsr_preprocess_bwd_views, views, nv, _ptr(coords.contiguous()),
           _ptr(scale_raw.contiguous()), _ptr(rot_raw.contiguous()), _ptr(opac_raw.contiguous()), _ptr(sh.contiguous()),
-          masks, sums, *[_ptr(g) for g in grads], screens, 1 if accumulate else 0, _stream(dev))
+          masks, sums, *[_ptr(g) for g in grads[:4]], None if g_colors is not None else _ptr(grads[4]), screens, colors,
+          1 if accumulate else 0, _stream(dev))
     return grads, g_screens
+
+
+def sh_grad_views(views, coords, sh, g_colors, g_sh, accumulate=False):
+    """``g_sh[N,3,16]`` of a view minibatch from the colour gradients of ALL its views
+    (``g_colors[v]``: ``[N,3]``, in the order of ``views``, a sequence of ``ViewSpec``)."""
+    import ctypes as C
+    lib = _lib.load()
+    n = coords.shape[0]
+    nv = len(views)
+    if len(g_colors) != nv:
+        raise ValueError(f"{len(g_colors)} colour gradients for {nv} views")
+    cviews = (_lib.GsrView * nv)(*[_lib.make_view(n, v.sh_degree, v.width, v.height, v.tile_length, v.w2m, v.proj, v.cam_pos)
+                                   for v in views])
+    cols = (C.c_void_p * nv)(*[_ptr(g) for g in g_colors])
+    _call("gsr_sh_grad_views", lib.gsr_sh_grad_views, cviews, nv, _ptr(coords.contiguous()), _ptr(sh.contiguous()), cols,
+          _ptr(g_sh), 1 if accumulate else 0, _stream(coords.device))
+    return g_sh
 
 
 class _Rasterize(torch.autograd.Function):

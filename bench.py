@@ -26,9 +26,9 @@ sys.path.insert(0, ROOT)
 
 import gsplat_amd  # noqa: E402,F401
 from gsplat_amd.camera import Camera  # noqa: E402
-from gsplat_amd.minibatch import GradBucket, render_views, shard_views  # noqa: E402
+from gsplat_amd.minibatch import GradBucket, reduce_gradients, render_views, shard_views  # noqa: E402
 from gsplat_amd.loss import loss_and_grad  # noqa: E402
-from gsplat_amd.rasterizer import StageTimer, ViewSpec  # noqa: E402
+from gsplat_amd.rasterizer import StageTimer, ViewSpec, sh_grad_views  # noqa: E402
 from gsplat_amd.scenes import synthetic_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
@@ -108,7 +108,8 @@ def main():
     params = [t.to(dev) for t in scene.params()]
     cams = minibatch_cameras(scene, args.views, dev)
     my_views = shard_views(args.views, world, rank)
-    views = [ViewSpec.from_camera(cams[v], args.sh_degree, args.tile) for v in my_views]
+    all_views = [ViewSpec.from_camera(c, args.sh_degree, args.tile) for c in cams]
+    views = [all_views[v] for v in my_views]
     gen = torch.Generator().manual_seed(1)
     # dL/dimg of loss = mean over the minibatch of sum(img * R_v)
     cots = [(torch.rand(args.width, args.height, 3, generator=gen) / args.views).to(dev) for _ in range(args.views)]
@@ -121,6 +122,10 @@ def main():
     # one flat fp32 bucket for the five parameter gradients (59 floats per Gaussian)
     bucket = GradBucket(n, dev)
     grads = list(bucket.views)
+
+    # With several ranks the sh gradient (48 of the 59 floats per Gaussian) is not exchanged: the ranks
+    # all-reduce the other 11 floats, all-gather 3 colour-gradient floats per view and rebuild it.
+    g_colors = torch.empty(len(views), n, 3, dtype=torch.float32, device=dev) if use_dist and not args.forward_only else None
 
     stats = {}
     model = opt = None
@@ -142,15 +147,16 @@ def main():
         # sorts and lists of the next views run beside the compositing of the current one; ONE pass then
         # chains all views to the raw parameters and writes the gradient bucket.
         states, _, g_screens = render_views(params, views, None if args.forward_only else cotangent,
-                                            grads=tuple(grads), overlap=overlap and not args.no_overlap)
+                                            grads=tuple(grads), overlap=overlap and not args.no_overlap,
+                                            g_colors=g_colors)
         if states and "m" not in stats:
             stats.update(m=states[0].num_visible, pairs=states[0].num_pairs)
         if args.forward_only:
             return
-        if use_dist and world == 1:
-            dist.all_reduce(bucket.flat)      # rehearsal: GradBucket skips the collective for one rank
-        else:
-            bucket.all_reduce()
+        if g_colors is not None:
+            reduce_gradients(bucket, g_colors, args.views,
+                             lambda g_all: sh_grad_views(all_views, params[0], params[4], list(g_all), bucket.sh),
+                             force_collectives=True)
         if opt is not None:
             # (each rank gathers the statistics of its own views; a trainer sums them over the ranks
             # before it densifies, every 50 iterations)
@@ -229,7 +235,8 @@ def main():
             "config": {
                 "workload": f"{n} synthetic Gaussians, SH degree {args.sh_degree}, {args.width}x{args.height}, "
                             f"tile {args.tile}, {args.views}-view minibatch {'forward only' if args.forward_only else 'fwd+bwd'} split over {world} GPU(s), "
-                            + ("RCCL all-reduce of the 59N-float gradient bucket" if world > 1 and not args.forward_only else "no collective")
+                            + ("RCCL all-reduce of 11N gradient floats + all-gather of 3N colour-gradient floats per view, sh gradient rebuilt on every rank"
+                               if world > 1 and not args.forward_only else "no collective")
                             + (", dL/dimg from the training loss kernel" if args.with_loss else "")
                             + (", densification statistics and fused Adam step" if args.train_iter else ""),
                 "gaussians": n, "width": args.width, "height": args.height, "tile_length": args.tile,

@@ -124,7 +124,22 @@ int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num_views, con
                              const float *scale_raw, const float *rot_raw, const float *opac_raw,
                              const float *sh, const uint8_t *const *mask_host, const float *const *gsum_host,
                              float *g_coords, float *g_scale, float *g_rot, float *g_opac, float *g_sh,
-                             float *const *g_screen_host, int accumulate, void *stream);
+                             float *const *g_screen_host, float *const *g_color_host, int accumulate,
+                             void *stream);
+
+/* The sh gradient of a view minibatch is a sum over the views of outer products: per Gaussian and
+ * colour channel, dL/d(colour of the view) times the view's SH basis (where the colour passes its
+ * clamp, GaussianRenderer.py:74).  Ranks that hold the same parameters therefore need not exchange
+ * the 48 sh gradient floats per Gaussian: gsr_preprocess_bwd_views with g_color_host != NULL also
+ * writes g_color_host[v][N,3], the colour gradient of view v as it reaches the clamp (zero rows where
+ * the Gaussian is culled), and with g_sh == NULL leaves the sh gradient out; after the ranks have
+ * gathered the colour gradients of ALL views of the minibatch, gsr_sh_grad_views rebuilds
+ * g_sh[N,3,16] (written, or with accumulate != 0 added to) with the arithmetic and the view order
+ * gsr_preprocess_bwd_views itself uses, so the result does not depend on the number of ranks.
+ * views_host: every view of the minibatch in minibatch order (camera positions and sh_degree are
+ * read); coords and sh: the parameters. */
+int gsr_sh_grad_views(const gsr_view *views_host, uint32_t num_views, const float *coords, const float *sh,
+                      const float *const *g_color_host, float *g_sh, int accumulate, void *stream);
 
 /* ---- stage 2: binning and sorting -----------------------------------------------------
  * Replaces Utils/Screen.py:38-62 (tile geometry + membership masks) and the per-tile argsort

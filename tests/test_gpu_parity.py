@@ -361,3 +361,52 @@ def test_render_views_pipelined_over_two_streams_matches_one_stream():
         assert len(got[3]) == len(ref[3]) and all(torch.equal(a, b) for a, b in zip(got[3], ref[3]))
     fwd_only, none_grads, no_screens = render_views(p, views, None)
     assert none_grads is None and no_screens == [] and torch.equal(fwd_only[0].img, ref[0][0])
+
+
+def test_factored_sh_gradient_equals_the_single_pass():
+    """Two emulated ranks: each renders half of the views, writes its colour gradients and leaves the sh
+    gradient out; summing the 11 small floats and rebuilding the sh gradient from the gathered colour
+    gradients reproduces the one-rank gradients (sh bit for bit: same arithmetic, same view order)."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.camera import Camera
+    from gsplat_amd.minibatch import SMALL_FLOATS, GradBucket, render_views, shard_views
+    from gsplat_amd.rasterizer import ViewSpec, sh_grad_views
+    from gsplat_amd.scenes import synthetic_scene
+    dev = _gpu()
+    for deg in (3, 1):
+        sc = synthetic_scene(20_000, 320, 208, deg, 12)
+        p = [t.to(dev) for t in sc.params()]
+        nv = 4
+        gen = torch.Generator().manual_seed(6)
+        cams = []
+        for v in range(nv):
+            ang = 2.0 * np.pi * v / nv
+            pos = np.array([0.25 * np.cos(ang) + (1000.0 if v == 2 else 0.0), 0.25 * np.sin(ang), 0.05 * v])   # view 2 sees nothing
+            cams.append(Camera(pos, np.array([1.0, 0.0, 0.0, 0.0]), sc.fx, sc.fy, sc.width / 2, sc.height / 2, sc.width,
+                               sc.height, device=dev))
+        cots = [torch.rand(sc.width, sc.height, 3, generator=gen).to(dev) for _ in range(nv)]
+        views = [ViewSpec.from_camera(c, deg, 16) for c in cams]
+        ref = GradBucket(sc.n, dev)
+        render_views(p, views, lambda i, st: cots[i], grads=ref.views)
+        small = torch.zeros(sc.n * SMALL_FLOATS, device=dev)
+        g_all = torch.full((nv, sc.n, 3), float("nan"), device=dev)
+        for rank in range(2):
+            mine = shard_views(nv, 2, rank)
+            b = GradBucket(sc.n, dev)
+            b.sh.fill_(float("nan"))     # must stay untouched
+            cols = torch.full((len(mine), sc.n, 3), float("nan"), device=dev)
+            render_views(p, [views[v] for v in mine], lambda i, st, mine=mine: cots[mine[i]], grads=b.views, g_colors=cols)
+            assert torch.isnan(b.sh).all()
+            small += b.flat[:sc.n * SMALL_FLOATS]          # what the all-reduce does
+            g_all[mine[0]:mine[-1] + 1] = cols              # what the all-gather does
+        assert not torch.isnan(g_all).any() and not g_all[2].any() and g_all[0].any()
+        out = GradBucket(sc.n, dev)
+        sh_grad_views(views, p[0], p[4], list(g_all), out.sh)
+        torch.cuda.synchronize()
+        assert torch.equal(out.sh, ref.sh)
+        K = (deg + 1) ** 2
+        assert not out.sh[:, :, K:].any() and out.sh[:, :, :K].any()
+        assert_close(small.cpu().numpy(), ref.flat[:sc.n * SMALL_FLOATS].cpu().numpy(), "coords/scale/rotation/opacity gradients")
+        # accumulate adds on top
+        sh_grad_views(views, p[0], p[4], list(g_all), out.sh, accumulate=True)
+        assert_close(out.sh.cpu().numpy(), 2 * ref.sh.cpu().numpy(), "accumulated sh gradient")

@@ -86,3 +86,57 @@ def test_two_rank_allreduce_matches_single_process(tmp_path):
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npy"))
         # fp32 reassociation only: (v0+v1)+(v2+v3) against ((v0+v1)+v2)+v3
         np.testing.assert_allclose(got, ref.flat.numpy(), rtol=1e-5, atol=1e-6 * float(np.abs(ref.flat.numpy()).max()))
+
+
+def _view_small_and_colour(view):
+    """(the 11 small gradient floats per Gaussian, flat in bucket order; a stand-in colour gradient [N,3])"""
+    g = _view_grads(view)
+    small = torch.cat([t.reshape(-1) for t in g[:4]])
+    colour = torch.rand(N_GAUSS, 3, generator=torch.Generator().manual_seed(900 + view)) - 0.5
+    return small, colour
+
+
+def _factored_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.minibatch import SMALL_FLOATS, GradBucket, reduce_gradients, shard_views
+    bucket = GradBucket(N_GAUSS, "cpu")
+    mine = shard_views(N_VIEWS, world, rank)
+    cols = torch.empty(len(mine), N_GAUSS, 3)
+    for k, v in enumerate(mine):
+        small, colour = _view_small_and_colour(v)
+        bucket.flat[:N_GAUSS * SMALL_FLOATS] += small
+        cols[k] = colour
+    bucket.sh.fill_(-7.0)       # the collectives must not touch the sh part
+    seen = {}
+    g_all = reduce_gradients(bucket, cols, N_VIEWS, lambda g: seen.setdefault("g", g.clone()))
+    assert torch.equal(seen["g"], g_all) and float(bucket.sh.min()) == -7.0 == float(bucket.sh.max())
+    np.save(os.path.join(out_dir, f"small{rank}.npy"), bucket.flat[:N_GAUSS * SMALL_FLOATS].numpy())
+    np.save(os.path.join(out_dir, f"colour{rank}.npy"), g_all.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_factored_exchange_moves_the_right_blocks(tmp_path):
+    """reduce_gradients: the small gradients are summed over the ranks, the colour gradients of all
+    views arrive on every rank in minibatch order, the sh part of the bucket is left to the rebuild."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_factored_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = [_view_small_and_colour(v) for v in range(N_VIEWS)]
+    want_small = sum(p[0] for p in parts).numpy()
+    want_colour = torch.stack([p[1] for p in parts]).numpy()
+    for r in range(2):
+        np.testing.assert_allclose(np.load(os.path.join(str(tmp_path), f"small{r}.npy")), want_small, rtol=1e-5,
+                                   atol=1e-6 * float(np.abs(want_small).max()))
+        np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), f"colour{r}.npy")), want_colour)
+
+
+def test_factored_exchange_needs_an_even_split():
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.minibatch import GradBucket, can_factor, reduce_gradients
+    assert can_factor(8, 1) and can_factor(8, 8) and not can_factor(8, 3)
+    with pytest.raises(ValueError):
+        reduce_gradients(GradBucket(5, "cpu"), torch.zeros(2, 4, 3), 2, lambda g: None)    # wrong Gaussian count
