@@ -146,16 +146,26 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
         const int xi = (int)(cur / (uint32_t)v.nbh), yi = (int)(cur - (uint32_t)xi * v.nbh);
         const float x0 = (float)(xi * v.L), y0 = (float)(yi * v.L);
         const float x1 = (float)(min((xi + 1) * v.L, v.W) - 1), y1 = (float)(min((yi + 1) * v.L, v.H) - 1);
-        bool low_top, low_bottom;
-        if (v.L == 16) {
-            // one compositing wave per tile: the halves of its 16x16 block are tested separately
-            const float ym = y0 + 7.0f;
-            low_top = tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, fminf(ym, y1));
-            low_bottom = ym >= y1 || tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, ym + 1.0f, y1);
+        // bits 2c and 2c+1: the top and bottom 8 rows of the tile's c-th 16x16 block (c = bx * S + by,
+        // the wave that composites it); a half that lies outside the tile counts as clamped
+        const int S = (v.L + 15) >> 4;
+        flags = 0u;
+        if (S <= 4) {
+            for (int bx = 0; bx < S; ++bx) {
+                const float bx0 = x0 + 16.0f * (float)bx, bx1 = fminf(bx0 + 15.0f, x1);
+                for (int by = 0; by < S; ++by) {
+                    const float by0 = y0 + 16.0f * (float)by, bym = by0 + 7.0f, by1 = fminf(by0 + 15.0f, y1);
+                    const bool none = bx0 > x1 || by0 > y1;
+                    const bool low_top = none || tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, bx0, bx1, by0, fminf(bym, by1));
+                    const bool low_bottom = none || bym >= by1 ||
+                                            tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, bx0, bx1, bym + 1.0f, by1);
+                    flags |= ((low_top ? 1u : 0u) | (low_bottom ? 2u : 0u)) << (2 * (bx * S + by));
+                }
+            }
         } else {
-            low_top = low_bottom = tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, y1);
+            // more than 16 blocks per tile: one test for the whole tile, the same answer for every block
+            flags = tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, y1) ? 0xFFFFFFFFu : 0u;
         }
-        flags = (low_top ? 1u : 0u) | (low_bottom ? 2u : 0u);
     }
     // stream layout: y x D' A' | o B' r ca | g slot b flags | cbh 0 cd 0
     out[0] = make_float4(a.y, a.x, b.x, a.z);

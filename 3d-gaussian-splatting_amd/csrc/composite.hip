@@ -24,9 +24,15 @@ namespace {
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr float kAlphaMin = 0.01f;
 constexpr float kAlphaMax = 0.99f;
-// Below this transmittance a pixel's remaining entries cannot change any fp32 result; the
-// backward stops dividing there (see composite_bwd_kernel).
-constexpr float kTinyT = 1e-20f;
+// The backward recovers the transmittance in front of an entry by dividing the one behind it, which
+// works for as long as the final transmittance is a normal fp32 number with room below it for the
+// exact remainder of the correctly rounded quotient (2^-24 of it).  A wave with a pixel whose final
+// transmittance is below this bound takes the checked sweep instead (see composite_bwd_kernel), which
+// also drops, per pixel, the entries behind the point where the transmittance falls below the bound:
+// their weights are below 1e-26 of the pixel's cotangent.  (The checked sweep re-runs the forward
+// recurrence and costs about three plain sweeps, so the bound sits as low as the arithmetic allows:
+// with every alpha at its floor of 0.01 a list needs 6000 entries to get there.)
+constexpr float kTinyT = 1e-26f;
 constexpr uint32_t kTouchAhead = 16;   // records (768 bytes) between the L2 touch and the scalar fetch
 
 struct WaveGeom {
@@ -35,6 +41,7 @@ struct WaveGeom {
     int ylim;            // rows < ylim are inside
     uint32_t begin, end; // list range (wave-uniform)
     uint32_t total;      // records in the whole stream
+    uint32_t flag_shift; // position of this block's two hint bits in a record's flags
 };
 
 // tile_order (may be null): the tiles in the order in which the waves of the grid take them - longest
@@ -54,6 +61,7 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
     const int xi = (int)(tile / (unsigned)v.nbh), yi = (int)(tile - (unsigned)xi * v.nbh);
     const int lane = threadIdx.x & 63;
     w.tile = (int)tile;
+    w.flag_shift = 2u * (sub & 15u);
     w.x = xi * v.L + sxi * 16 + (lane >> 2);
     w.y0 = yi * v.L + syi * 16 + (lane & 3);
     const int xlim = min((xi + 1) * v.L, v.W);
@@ -117,10 +125,16 @@ __device__ inline void l2_touch(const float *stream_rec, uint32_t off, uint32_t 
 }
 __device__ inline void l2_touch_drain(float &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
 
-// Hint flags of a record: the halves of the 16x16 block on which alpha is pinned at 0.01 for every
-// pixel (bit 0: top 8 rows, bit 1: bottom 8 rows; for tiles larger than one block both bits
-// describe the whole tile).  Wave-uniform: scalar compares and branches.
+// Hint flags of a record: the halves of a 16x16 block on which alpha is pinned at 0.01 for every
+// pixel (bit 0: top 8 rows, bit 1: bottom 8 rows).  A tile of up to 4x4 blocks carries two bits per
+// block, block c at bits 2c and 2c+1 (MULTI: the wave shifts its own pair down; a tile that is one block
+// has them at bits 0 and 1).  Wave-uniform: scalar compares and branches.
 constexpr uint32_t kLowTop = 1u, kLowBottom = 2u, kLowBoth = 3u;
+template <bool MULTI>
+__device__ inline uint32_t block_flags(uint32_t record_flags, uint32_t shift)
+{
+    return MULTI ? (record_flags >> shift) & 3u : record_flags;
+}
 
 __device__ inline float clamp_alpha(float raw) { return fminf(fmaxf(raw, kAlphaMin), kAlphaMax); }
 
@@ -133,6 +147,7 @@ __device__ inline f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma
 __device__ inline f2 exp2_2(f2 q) { return f2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)}; }
 __device__ inline f2 clamp_alpha2(f2 raw) { return f2{clamp_alpha(raw.x), clamp_alpha(raw.y)}; }
 
+template <bool MULTI>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                             const uint32_t *__restrict__ tile_order,
                                                             const float *__restrict__ stream_rec,
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     };
     auto blend = [&](const Rec &R) {
         const float red = R_r(R);
-        if (R_flags(R) == kLowBoth) {
+        if (block_flags<MULTI>(R_flags(R), w.flag_shift) == kLowBoth) {
             half_low(0, R, red);
             half_low(1, R, red);
             return;
@@ -424,7 +439,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     };
     auto entry = [&](const Rec &R, uint32_t k) {
         const uint32_t rec_off = R_slot(R) * (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));   // a Gaussian's records are contiguous
-        const uint32_t flags = R_flags(R);
+        const uint32_t flags = block_flags<ATOMIC>(R_flags(R), w.flag_shift);   // ATOMIC = several blocks per tile
         const f2 z = splat(0.f);
         s_r = s_g = s_b = z;
         const float red = R_r(R);
@@ -480,10 +495,12 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
 
 // ATOMIC = several waves share a tile (L > 16): their sums meet in pairgrad through float atomics
 // (pairgrad zeroed by the launcher).  Otherwise each record is written once with plain stores.
-// The kernel is launched twice.  TINY = false handles the waves none of whose pixels ran below
-// kTinyT and returns at once in the others; TINY = true does the opposite.  The plain sweep then
-// does not pay (in registers, hence in waves per SIMD) for the rarely needed checked one.
-template <bool TINY, bool ATOMIC>
+// A wave none of whose pixels ran below kTinyT takes the plain sweep, the others the checked one.
+// Both live in one launch: the checked waves are few and three times as long, and a launch of their
+// own ran at the latency of a single wave per SIMD.  (Four waves per SIMD: the loop is bound by
+// instruction issue, more resident waves do not help it, and the register budget of four waves
+// holds both sweeps.)
+template <bool ATOMIC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                             const uint32_t *__restrict__ tile_order,
                                                             const float *__restrict__ stream_rec,
@@ -512,21 +529,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     uint32_t nstop[4] = {0u, 0u, 0u, 0u};
-    if ((__ballot(tiny) != 0ull) != TINY) return;
-    if (TINY) {
+    if (__ballot(tiny) != 0ull) {
         // Some pixel's transmittance ran below kTinyT (long or opaque lists; it may have underflowed
         // to zero, where dividing back is impossible).  Re-run the forward recurrence to find, per
         // pixel, the entry after which T < kTinyT and the T there; later entries are dropped for
-        // that pixel: their weights are below 1e-20 of the pixel's cotangent.
+        // that pixel: their weights are below 1e-26 of the pixel's cotangent.
         const uint32_t len = w.end - w.begin;
         float Tf[4], Ts[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Tf[j] = 1.0f; Ts[j] = 0.0f; nstop[j] = len; }
-        for (uint32_t k = w.begin; k < w.end; ++k) {
-            Rec R;
-            rec_request(stream_rec, k * 64u, R);
-            rec_wait(R);
-            const bool low[2] = {(R_flags(R) & kLowTop) != 0, (R_flags(R) & kLowBottom) != 0};
+        auto forward_step = [&](const Rec &R, uint32_t idx) {
+            const uint32_t bf = block_flags<ATOMIC>(R_flags(R), w.flag_shift);
+            const bool low[2] = {(bf & kLowTop) != 0, (bf & kLowBottom) != 0};
             const float o = R_o(R);
             const float dx = R_gx(R) - pxf;
             const float adx2 = R_A(R) * dx * dx;
@@ -538,9 +552,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const float a = low[j >> 1] ? kAlphaMin : clamp_alpha(o * __builtin_amdgcn_exp2f(q));
                 Tf[j] = Tf[j] * (1.0f - a);
                 const bool hit = (Tf[j] < kTinyT) && (nstop[j] == len);
-                nstop[j] = hit ? (k - w.begin + 1u) : nstop[j];
+                nstop[j] = hit ? (idx + 1u) : nstop[j];
                 Ts[j] = hit ? Tf[j] : Ts[j];
             }
+        };
+        {
+            // front to back with two record buffers and the L2 touch-ahead, as in composite_fwd_kernel: a
+            // loop that waits for every record before it asks for the next one runs at the latency of L2
+            const uint32_t off_last = (w.end - 1) * 64u, off_stream_last = (w.total - 1) * 64u;
+            const uint32_t touch_off = (threadIdx.x & 1) ? 0u - 64u : 0u;
+            uint32_t off = w.begin * 64u, idx = 0u;
+            float sink = 0.0f;
+            Rec A, B;
+            rec_request(stream_rec, off, A);
+            for (;;) {
+                rec_wait(A);
+                uint32_t next = min(off + 64u, off_last);
+                rec_request(stream_rec, next, B);
+                l2_touch(stream_rec, min(off + kTouchAhead * 64u, off_stream_last), touch_off, sink);
+                forward_step(A, idx);
+                if (off == off_last) break;
+                off = next;
+                ++idx;
+                rec_wait(B);
+                next = min(off + 64u, off_last);
+                rec_request(stream_rec, next, A);
+                forward_step(B, idx);
+                if (off == off_last) break;
+                off = next;
+                ++idx;
+            }
+            rec_wait(A);
+            rec_wait(B);
+            l2_touch_drain(sink);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -563,8 +607,12 @@ extern "C" int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile
     if (!tile_offsets || !img || !final_T) { gsr_set_error("gsr_composite_fwd: null pointer"); return GSR_ERR_ARG; }
     const int S = (v.L + 15) >> 4;
     const unsigned waves = (unsigned)v.T * S * S;
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(gsr_div_up(waves, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, img, final_T);
+    if (S > 1)
+        hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(gsr_div_up(waves, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
+                           (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, img, final_T);
+    else
+        hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(gsr_div_up(waves, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
+                           (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, img, final_T);
     return gsr_check_launch("composite_fwd");
 }
 
@@ -588,15 +636,11 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
     const dim3 grid(gsr_div_up(waves, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
     if (S > 1) {
         (void)hipMemsetAsync(pairgrad, 0, (size_t)num_pairs * GSR_PAIRGRAD_FLOATS * sizeof(float), (hipStream_t)stream);
-        hipLaunchKernelGGL((composite_bwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           tile_order, stream_rec, final_T, dimg, pairgrad);
-        hipLaunchKernelGGL((composite_bwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           tile_order, stream_rec, final_T, dimg, pairgrad);
+        hipLaunchKernelGGL((composite_bwd_kernel<true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
+                           stream_rec, final_T, dimg, pairgrad);
     } else {
-        hipLaunchKernelGGL((composite_bwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           tile_order, stream_rec, final_T, dimg, pairgrad);
-        hipLaunchKernelGGL((composite_bwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets,
-                           tile_order, stream_rec, final_T, dimg, pairgrad);
+        hipLaunchKernelGGL((composite_bwd_kernel<false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
+                           stream_rec, final_T, dimg, pairgrad);
     }
     return gsr_check_launch("composite_bwd");
 }

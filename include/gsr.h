@@ -62,8 +62,10 @@ typedef struct gsr_counters {
  *   0 y   1 x   2 D'   3 A'   4 opacity   5 B'   6 r   7 a   8 g   9 slot (u32)   10 b
  *   11 flags (u32)   12 (b+c)/2   13 0   14 d   15 0
  * slot  = the pair's emission slot (row of pairgrad its gradient record goes to);
- * flags = hints: bit 0 / bit 1 set when alpha is 0.01 on every pixel of the top / bottom 8 rows of
- *         a 16x16 tile (for other tile sizes both bits describe the whole tile). */
+ * flags = hints for the compositing waves: a tile of edge L is composited by S*S waves, S = ceil(L/16),
+ *         one per 16x16 block (block c = bx * S + by); bits 2c / 2c+1 are set when alpha is 0.01 on
+ *         every pixel of the top / bottom 8 rows of block c (S <= 4; for larger tiles all 32 bits
+ *         carry the answer for the whole tile). */
 #define GSR_STREAM_DWORDS 16
 /* Per-(tile,Gaussian) gradient record produced by the compositing backward. */
 /* With h = -2 dL/d(exponent) per pixel, d = centre - pixel and v = inverse covariance * d:

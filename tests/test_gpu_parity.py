@@ -245,7 +245,7 @@ def test_huge_splats_cover_every_tile(oracle_mod):
 @pytest.mark.parametrize("tile", [16, 64])
 def test_opaque_stack_underflows_the_transmittance(oracle_mod, tile):
     """Many opaque splats on top of each other: the final transmittance of most pixels is far below
-    1e-20 (down to 0), so the backward cannot divide its way back and takes the checked sweep."""
+    1e-26 (down to 0), so the backward cannot divide its way back and takes the checked sweep."""
     import gsplat_amd  # noqa: F401
     from gsplat_amd.scenes import synthetic_scene
     sc = synthetic_scene(600, 96, 80, 2, 5)
@@ -254,7 +254,7 @@ def test_opaque_stack_underflows_the_transmittance(oracle_mod, tile):
     a["opacity"] = np.full_like(a["opacity"], 6.0)
     cot = torch.rand(96, 80, 3, generator=torch.Generator().manual_seed(7)).numpy()
     hip = run_hip(cot=cot, tile=tile, **a)
-    assert (hip["final_T"] < 1e-20).mean() > 0.5 and (hip["final_T"] == 0).any()
+    assert (hip["final_T"] < 1e-26).mean() > 0.5 and (hip["final_T"] == 0).any()
     ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 2, 96, 80, tile, a["w2m"],
                             a["proj"], a["cam_pos"], dimg=cot)
     compare(hip, ora)
