@@ -86,7 +86,7 @@ def load():
     vp = C.c_void_p
     lib.gsr_preprocess_fwd.argtypes = [C.POINTER(GsrView)] + [vp] * 16
     lib.gsr_preprocess_bwd.argtypes = [C.POINTER(GsrView)] + [vp] * 15 + [C.c_int, vp, C.c_size_t, vp]
-    lib.gsr_pair_reduce.argtypes = [C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_pair_reduce.argtypes = [C.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.gsr_preprocess_bwd_views.argtypes = ([C.POINTER(GsrView), C.c_uint32] + [vp] * 5 + [C.POINTER(vp)] * 2 + [vp] * 5 +
                                              [C.POINTER(vp), C.POINTER(vp), C.c_int, vp])
     lib.gsr_sh_grad_views.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, C.POINTER(vp), vp, C.c_int, vp]

@@ -303,8 +303,7 @@ def backward_records(st: RenderState, dimg) -> torch.Tensor:
     pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
     _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
     gsum = torch.empty(st.n, 12, **f32)
-    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), None, None,   # (index order: measured faster than depth order)
-          _ptr(pairgrad),
+    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad),
           _ptr(gsum), stream)
     return gsum
 

@@ -114,14 +114,11 @@ int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const flo
  * num_views views (host arrays of per-view device pointers) to the raw parameters in one pass: the
  * dense gradients are written (accumulate == 0) or added to (accumulate != 0) ONCE for all views,
  * where per-view calls of gsr_preprocess_bwd re-read and re-write them for every view.
- * gsr_pair_reduce's order and slot_seq (both from gsr_bin_offsets; both may be NULL) let it walk the
- * Gaussians in depth order, in which their records are consecutive in memory; the sums are the same.
  * g_screen_host[v][N,3] receives view v's screen_coords gradient.  All views must share n and
  * sh_degree.  At most GSR_MAX_VIEWS views go into one kernel launch; more are processed in groups. */
 #define GSR_MAX_VIEWS 8
 int gsr_pair_reduce(uint32_t n, const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
-                    const uint32_t *order, const uint32_t *slot_seq, const float *pairgrad, float *gsum,
-                    void *stream);
+                    const float *pairgrad, float *gsum, void *stream);
 int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num_views, const float *coords,
                              const float *scale_raw, const float *rot_raw, const float *opac_raw,
                              const float *sh, const uint8_t *const *mask_host, const float *const *gsum_host,
