@@ -25,14 +25,17 @@ constexpr int WAVES_PER_BLOCK = 4;
 constexpr float kAlphaMin = 0.01f;
 constexpr float kAlphaMax = 0.99f;
 // The backward recovers the transmittance in front of an entry by dividing the one behind it, which
-// works for as long as the final transmittance is a normal fp32 number with room below it for the
-// exact remainder of the correctly rounded quotient (2^-24 of it).  A wave with a pixel whose final
-// transmittance is below this bound takes the checked sweep instead (see composite_bwd_kernel), which
-// also drops, per pixel, the entries behind the point where the transmittance falls below the bound:
-// their weights are below 1e-26 of the pixel's cotangent.  (The checked sweep re-runs the forward
-// recurrence and costs about three plain sweeps, so the bound sits as low as the arithmetic allows:
-// with every alpha at its floor of 0.01 a list needs 6000 entries to get there.)
+// works for as long as the transmittance is a normal fp32 number with room below it for the exact
+// remainder of the correctly rounded quotient (2^-24 of it): kTinyT.  A wave whose smallest final
+// transmittance lies between the smallest normal number and kTinyT scales its transmittances up by
+// kRescue (a power of two, exact) and still takes the plain sweep.  Only a wave with a pixel whose
+// transmittance went denormal or to zero takes the checked sweep (see composite_bwd_kernel), which
+// re-runs the forward recurrence, costs about two plain sweeps, and drops, per pixel, the entries
+// behind the point where the transmittance falls below kTinyT: their weights are below 1e-26 of the
+// pixel's cotangent.
 constexpr float kTinyT = 1e-26f;
+constexpr float kMinNormalT = 1.17549435e-38f;   // FLT_MIN
+constexpr float kRescue = 1099511627776.0f;      // 2^40: FLT_MIN * 2^40 > kTinyT
 constexpr uint32_t kTouchAhead = 16;   // records (768 bytes) between the L2 touch and the scalar fetch
 
 struct WaveGeom {
@@ -327,8 +330,8 @@ __device__ inline void put_record(float *pairgrad, uint32_t rec_off, uint32_t la
 // Full record, floats: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2, dL/d(opacity),
 // dL/d(red), dL/d(green), then four partial sums of dL/d(blue).
 template <bool ATOMIC>
-__device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, uint32_t rec_off, float vx, float vy,
-                                         float xx, float xy, float yy, float o, float r, float g, float b)
+__device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, uint32_t rec_off, float unscale, float vx,
+                                         float vy, float xx, float xy, float yy, float o, float r, float g, float b)
 {
     // pairing order chosen so that group g of 8 lanes ends up with record float g
     const float m0 = merge_halves(vx, yy), m1 = merge_halves(xx, r), m2 = merge_halves(vy, o), m3 = merge_halves(xy, g);
@@ -336,16 +339,16 @@ __device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, 
     const float n1 = merge_rows(m2, m3);   // rows: vy, xy, o,  g
     const float all8 = sum8(merge_half_rows(n0, n1));
     const float blue = sum16(b);
-    put_record<ATOMIC>(pairgrad, rec_off, L.full_off, L.full_main ? all8 : blue, kFullWriters);
+    put_record<ATOMIC>(pairgrad, rec_off, L.full_off, (L.full_main ? all8 : blue) * unscale, kFullWriters);
 }
 
 // Colour-only record (the clamp blocks every other gradient of the entry).
 template <bool ATOMIC>
-__device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad, uint32_t rec_off, float r, float g,
-                                           float b)
+__device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad, uint32_t rec_off, float unscale, float r,
+                                           float g, float b)
 {
     const float rows = sum16(merge_rows(merge_halves(r, g), b));   // rows: red, blue(0-1), green, blue(2-3)
-    put_record<ATOMIC>(pairgrad, rec_off, L.col_off, L.col_zero ? 0.0f : rows, kColWriters);
+    put_record<ATOMIC>(pairgrad, rec_off, L.col_off, L.col_zero ? 0.0f : rows * unscale, kColWriters);
 }
 
 // Reverse sweep of one list for the 4 pixels of a lane.  CHECK: pixel j only takes part in
@@ -353,7 +356,8 @@ __device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad
 template <bool CHECK, bool ATOMIC>
 __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ stream_rec, const float pxf,
                                  const f2 (&pyf)[2], f2 (&T)[2], const f2 (&gr)[2], const f2 (&gg)[2],
-                                 const f2 (&gb)[2], const uint32_t (&nstop)[4], float *__restrict__ pairgrad)
+                                 const f2 (&gb)[2], const uint32_t (&nstop)[4], const float unscale,
+                                 float *__restrict__ pairgrad)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
     const f2 py_top = pyf[0];
@@ -446,7 +450,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         if (flags == kLowBoth) {
             half_low(0, R, k, red);
             half_low(1, R, k, red);
-            reduce_store_colour<ATOMIC>(lanes, pairgrad, rec_off, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+            reduce_store_colour<ATOMIC>(lanes, pairgrad, rec_off, unscale, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
             return;
         }
         s_vx = s_vy = s_xx = s_xy = s_yy = s_o = z;
@@ -458,7 +462,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         if (flags & kLowBottom) half_low(1, R, k, red); else half_full(1, R, k, red, o, dx, adx2, bdx);
         // (an entry that is not flagged but whose clamp blocks every pixel anyway - one in a thousand -
         // simply stores zero sums)
-        reduce_store_full<ATOMIC>(lanes, pairgrad, rec_off, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
+        reduce_store_full<ATOMIC>(lanes, pairgrad, rec_off, unscale, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
                                   s_yy.x + s_yy.y, s_o.x + s_o.y, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
     };
     // back to front, two record buffers alternating (see composite_fwd_kernel); k is only needed by
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     raise_wave_priority();
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], gr[2], gg[2], gb[2];
-    bool tiny = false;
+    bool tiny = false, small = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int y = w.y0 + 4 * j;   // j = 0, 1: top half of the block; 2, 3: bottom half
@@ -525,13 +529,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const size_t pix = (size_t)w.x * v.H + y;
             T[h][e] = final_T[pix];
             gr[h][e] = dimg[pix * 3 + 0]; gg[h][e] = dimg[pix * 3 + 1]; gb[h][e] = dimg[pix * 3 + 2];
-            tiny |= !(T[h][e] >= kTinyT);
+            small |= !(T[h][e] >= kTinyT);
+            tiny |= !(T[h][e] >= kMinNormalT);
         }
     }
     uint32_t nstop[4] = {0u, 0u, 0u, 0u};
     if (__ballot(tiny) != 0ull) {
-        // Some pixel's transmittance ran below kTinyT (long or opaque lists; it may have underflowed
-        // to zero, where dividing back is impossible).  Re-run the forward recurrence to find, per
+        // Some pixel's transmittance went denormal or underflowed to zero (long or opaque lists), where
+        // dividing back is impossible.  Re-run the forward recurrence to find, per
         // pixel, the entry after which T < kTinyT and the T there; later entries are dropped for
         // that pixel: their weights are below 1e-26 of the pixel's cotangent.
         const uint32_t len = w.end - w.begin;
@@ -591,9 +596,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const bool inside = w.vx && (w.y0 + 4 * j) < w.ylim;
             if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
-        bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad);
+        bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, 1.0f, pairgrad);
     } else {
-        bwd_sweep<false, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad);
+        // Between kTinyT and the smallest normal number the plain sweep still works on a transmittance
+        // scaled by a power of two (exact): everything the sweep accumulates is linear in T, so the sums
+        // of the wave come out scaled by the same factor and are scaled back when a record is stored.
+        float unscale = 1.0f;
+        if (__ballot(small) != 0ull) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) T[h] = T[h] * splat(kRescue);
+            unscale = 1.0f / kRescue;
+        }
+        bwd_sweep<false, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, unscale, pairgrad);
     }
 }
 

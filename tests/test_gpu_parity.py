@@ -242,6 +242,31 @@ def test_huge_splats_cover_every_tile(oracle_mod):
     compare(hip, ora)
 
 
+@pytest.mark.parametrize("n,tile", [(30_000, 16), (40_000, 16), (15_000, 64)])
+def test_long_lists_take_the_rescaled_plain_sweep(oracle_mod, n, tile):
+    """Thousands of entries per list: the final transmittance of most blocks lies between the smallest
+    normal fp32 number and 1e-26, where the backward divides its way back on transmittances scaled up by
+    a power of two.  At 30 k the other blocks are above 1e-26 (unscaled plain sweep), at 40 k they have a
+    denormal or zero pixel (checked sweep)."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.scenes import synthetic_scene
+    sc = synthetic_scene(n, 128, 96, 1, 17)
+    a = _scene_arrays(sc)
+    a["opacity"] = a["opacity"].copy() - 1.0
+    cot = torch.rand(128, 96, 3, generator=torch.Generator().manual_seed(7)).numpy()
+    hip = run_hip(cot=cot, tile=tile, **a)
+    blocks = hip["final_T"].reshape(8, 16, 6, 16).min(axis=(1, 3))
+    rescued = (blocks < 1e-26) & (blocks >= 1.2e-38)
+    if tile == 16:
+        assert rescued.mean() > 0.5, f"only {rescued.mean():.2f} of the blocks exercise the rescaled sweep"
+        assert ((blocks >= 1e-26).any(), (blocks < 1.2e-38).any()) == ((True, False) if n == 30_000 else (False, True))
+    else:
+        assert rescued.any()
+    ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 1, 128, 96, tile, a["w2m"],
+                            a["proj"], a["cam_pos"], dimg=cot)
+    compare(hip, ora)
+
+
 @pytest.mark.parametrize("tile", [16, 64])
 def test_opaque_stack_underflows_the_transmittance(oracle_mod, tile):
     """Many opaque splats on top of each other: the final transmittance of most pixels is far below
