@@ -47,8 +47,8 @@ class GaussianModel(GaussianParams):
     """The reference ``GaussianModel``'s training-state surface (``GaussianModel.py:14-245``) on the
     GPU: capacity rows of which ``_size`` are live, the densification statistics and the methods the
     trainer calls around a render (``Trainer.py:60-74``).  Each method does what the reference's
-    method of the same name does, through the kernels behind ``densify.py``.  Point-cloud
-    construction and PLY I/O are not part of it."""
+    method of the same name does, through the kernels behind ``densify.py`` (PLY I/O: ``ply.py``).
+    Point-cloud construction is not part of it."""
 
     def __init__(self, coords, scale, rotation, opacity, sh, sh_degree: int = 0, max_sh_degree: int = 3, size=None):
         super().__init__(coords, scale, rotation, opacity, sh, sh_degree, max_sh_degree)
@@ -102,6 +102,16 @@ class GaussianModel(GaussianParams):
     def remove(self, mask, inplace: bool = True):
         from . import densify as D
         return D.remove(self, mask, inplace)
+
+    def save_ply(self, path: str):
+        """``GaussianModel.save_ply`` (``GaussianModel.py:268-281``)."""
+        from . import ply
+        ply.save_ply(self, path)
+
+    def load_ply(self, path: str):
+        """``GaussianModel.load_ply`` (``GaussianModel.py:283-318``)."""
+        from . import ply
+        ply.load_ply(self, path, device=self._coords.device)
 
     def capture(self, optimizer):
         """``GaussianModel.capture`` (``GaussianModel.py:320-331``)."""
