@@ -8,7 +8,7 @@ One step = one pass of the hot path over one view minibatch: every view is rende
 backward (all five parameter gradients + the screen_coords gradient), the parameter gradients of
 the rank's views are accumulated in one flat bucket, and with N > 1 ranks the bucket is summed
 over ranks with one RCCL all-reduce.  The 8 views of the minibatch are split contiguously over the
-ranks (strong scaling: the minibatch is fixed, as BASELINE.json's config 3 states it).
+ranks (strong scaling: the minibatch is fixed at 8 views).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -48,7 +48,9 @@ def minibatch_cameras(scene, n_views, device):
 
 
 def algorithmic_bytes(n, m, pairs, pixels, k_sh):
-    """Compulsory HBM bytes per view of each stage (formulas stated in DESIGN.md)."""
+    """Compulsory HBM bytes per view of each stage: n Gaussians (m visible) with 236-byte parameter rows
+    and 64-byte per-Gaussian outputs, `pairs` (tile, Gaussian) pairs at 44 bytes per compositing read,
+    `pixels` pixels, k_sh active SH coefficients per channel."""
     return {
         "preprocess_fwd": n * (12 + 12 + 16 + 4 + 12 * k_sh) + n + m * 64,
         "binning_sort": m * 16 + pairs * 12 + 2 * pairs * 12 + pairs * 8,

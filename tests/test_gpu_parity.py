@@ -128,7 +128,7 @@ def test_mid_size_vs_oracle(oracle_mod, kind, n, w, h, deg, tile):
 
 
 def test_config2_200k_800x800_vs_oracle(oracle_mod):
-    """BASELINE config 2: 200k Gaussians, SH degree 3, one 800x800 view, forward + backward."""
+    """The single-view parity configuration: 200k Gaussians, SH degree 3, one 800x800 view, forward + backward."""
     import gsplat_amd  # noqa: F401
     from gsplat_amd.scenes import synthetic_scene
     sc = synthetic_scene(200_000, 800, 800, 3, 0)
@@ -184,7 +184,7 @@ def test_singular_covariance_is_an_error():
 
 
 def test_config3_1m_1080p_vs_oracle(oracle_mod):
-    """BASELINE config 3, one view of the minibatch at full size: 1 M Gaussians, 1920x1080, tile 16,
+    """The headline configuration, one view of the minibatch at full size: 1 M Gaussians, 1920x1080, tile 16,
     forward + backward, every discrete result bit-exact and every float within tolerance."""
     import gsplat_amd  # noqa: F401
     from gsplat_amd.scenes import synthetic_scene
@@ -213,7 +213,7 @@ def test_config3_1m_1080p_vs_oracle(oracle_mod):
 
 
 def test_config5_6m_4k_forward_vs_oracle(oracle_mod):
-    """BASELINE config 5 (stress), one view at full size: 6 M Gaussians, 3840x2160, tile 16, forward
+    """The forward-only stress configuration, one view at full size: 6 M Gaussians, 3840x2160, tile 16, forward
     only (32 M pairs, a 2 GiB record stream): discrete results bit-exact, the image within tolerance."""
     import gsplat_amd  # noqa: F401
     from gsplat_amd.scenes import synthetic_scene
