@@ -6,8 +6,9 @@
 
 One step = one pass of the hot path over one view minibatch: every view is rendered forward and
 backward (all five parameter gradients + the screen_coords gradient), the parameter gradients of
-the rank's views are accumulated in one flat bucket, and with N > 1 ranks the bucket is summed
-over ranks with one RCCL all-reduce.  The 8 views of the minibatch are split contiguously over the
+the rank's views are accumulated in one flat bucket, and with N > 1 ranks the gradients are exchanged
+over RCCL (all-reduce of the 11 coords/scale/rotation/opacity floats per Gaussian, all-gather of the 3
+colour-gradient floats per view from which every rank rebuilds the sh gradient).  The 8 views of the minibatch are split contiguously over the
 ranks (strong scaling: the minibatch is fixed at 8 views).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
