@@ -280,3 +280,54 @@ def test_training_iteration_runs_end_to_end():
         losses.append(float(loss.detach()))
     assert int(model._denom[:3000].max()) >= 1 or model._size > 3000
     assert losses[3] < losses[0] and all(np.isfinite(losses))
+
+
+class _RingLoader:
+    """Stand-in for the reference's DataLoader (Utils/DataLoader.py:72-106): sample() and scene_radius."""
+
+    def __init__(self, scene, targets, cams, radius):
+        self.scene, self.targets, self.cams, self.k = scene, targets, cams, 0
+        self.scene_radius = np.array([radius, 0.5 * radius], np.float32)
+
+    def sample(self, is_train=True):
+        self.k = (self.k + 1) % len(self.cams)
+        return self.cams[self.k], self.targets[self.k]
+
+
+def test_trainer_loop_with_densification():
+    """Trainer.train (Trainer.py:47-89) for 120 iterations: two densification rounds (iterations 50 and
+    100) grow the model and its capacity and the optimiser follows.  The loss falls until the first
+    densification; after it the reference's clone (a second copy on top of the first) and split (new
+    centres around the origin) make the picture worse before training recovers, so the end is only
+    required to be finite."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.camera import Camera
+    from gsplat_amd.model import GaussianModel
+    from gsplat_amd.renderer import GaussianRenderer
+    from gsplat_amd.scenes import synthetic_scene
+    from gsplat_amd.trainer import Trainer
+    sc = synthetic_scene(2000, 96, 64, 1, seed=8)
+    p = [t.to(dev()) for t in sc.params()]
+    cams = []
+    for v in range(4):
+        ang = 2.0 * np.pi * v / 4
+        cams.append(Camera(np.array([0.1 * np.cos(ang), 0.1 * np.sin(ang), 0.0]), np.array([1.0, 0.0, 0.0, 0.0]), sc.fx, sc.fy,
+                           sc.width / 2, sc.height / 2, sc.width, sc.height, device=dev()))
+    truth = GaussianRenderer(GaussianModel(*p, sh_degree=1))
+    with torch.no_grad():
+        targets = [truth(c, 16)[0].clone() for c in cams]
+    gen = torch.Generator().manual_seed(2)
+    start = [p[0] + 0.02 * torch.randn(p[0].shape, generator=gen).to(dev()), p[1], p[2], p[3] - 0.5,
+             p[4] + 0.1 * torch.randn(p[4].shape, generator=gen).to(dev())]
+    model = GaussianModel(*start, sh_degree=1)
+    trainer = Trainer(model, _RingLoader(sc, targets, cams, radius=0.05), lr=2e-3, train_steps=120, tile_length=16)
+    assert float(trainer.scene_radius) == pytest.approx(0.05)
+    first = float(trainer.evaluate())
+    losses = trainer.train()
+    assert len(losses) == 12 and all(np.isfinite(losses))
+    assert model._size > 2000 and model.capacity >= model._size            # densified, capacity grown
+    assert trainer.optimizer.exp_avg[0].shape[0] == model.capacity         # the optimiser followed the growth
+    assert [id(q) for q in trainer.optimizer.params] == [id(q) for q in model.parameters()]
+    assert float(model._denom.max()) <= 20                                 # statistics restarted at iteration 100
+    assert losses[3] < 0.5 * first and np.isfinite(float(trainer.evaluate()))
+    assert trainer.get_image_scale(0) == 0.25 and trainer.get_image_scale(300) == 0.5 and trainer.get_image_scale(900) == 1
