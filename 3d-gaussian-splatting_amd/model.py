@@ -58,6 +58,31 @@ class GaussianModel(GaussianParams):
         self._coords_grads = torch.zeros((cap, 1), dtype=torch.float32, device=coords.device)
         self._denom = torch.zeros((cap, 1), dtype=torch.int32, device=coords.device)
 
+    @staticmethod
+    def from_pcd(pcd, device="cuda", max_sh_degree: int = 3) -> "GaussianModel":
+        """``GaussianModel.from_pcd`` (``GaussianModel.py:71-97``): one Gaussian per point of a point cloud
+        (an object with ``coords`` ``[N,3]`` and ``colors`` ``[N,>=3]`` in 0..255, like the reference's
+        ``PointCloud``): raw opacity 1, the colour in the first sh coefficient, an isotropic scale of the
+        root of the mean squared distance to the three nearest points (``gsr_knn_dist2`` in place of
+        ``simple_knn``'s ``distCUDA2``), the identity rotation, SH degree 0."""
+        import numpy as np
+        from . import _lib
+        from .rasterizer import _call, _stream
+        dev = torch.device(device)
+        coords = torch.as_tensor(np.asarray(pcd.coords), dtype=torch.float32).to(dev).contiguous()
+        n = coords.shape[0]
+        colors = torch.as_tensor(np.asarray(pcd.colors)[:, :3].astype(np.float32)).to(dev)
+        sh = torch.zeros((n, 3, (max_sh_degree + 1) ** 2), dtype=torch.float32, device=dev)
+        sh[:, :, 0] = (colors / 255 - 0.5) / 0.28209479177387814          # RGB2SH, Utils/SphericalHarmonic.py:6-7,14
+        dist2 = torch.empty(n, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _call("gsr_knn_dist2", lib.gsr_knn_dist2, n, coords.data_ptr(), dist2.data_ptr(), _stream(dev))
+        scale = torch.log(torch.sqrt(torch.clamp_min(dist2, 0.0000001)))[..., None].repeat(1, 3)
+        rotation = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        rotation[:, 0] = 1
+        opacity = torch.ones((n, 1), dtype=torch.float32, device=dev)
+        return GaussianModel(coords, scale, rotation, opacity, sh, sh_degree=0, max_sh_degree=max_sh_degree)
+
     @property
     def capacity(self):
         return self._coords.shape[0]

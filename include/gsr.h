@@ -294,6 +294,13 @@ int gsr_remove_apply(uint32_t size, uint32_t num_removed, const uint8_t *mask, c
                      float *coords_grads, int32_t *denom, void *workspace, size_t workspace_bytes,
                      void *stream);
 
+/* ---- initialisation from a point cloud ------------------------------------------------------
+ * Replaces distCUDA2 of the simple_knn extension as GaussianModel.from_pcd calls it
+ * (GaussianModel.py:82): dist2[i] = mean of the squared distances from points[i] to its three nearest
+ * other points (a point's own index is skipped; coincident points count with distance zero).
+ * points[N,3], dist2[N]; N >= 4.  Exhaustive search, O(N^2). */
+int gsr_knn_dist2(uint32_t n, const float *points, float *dist2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -331,3 +331,46 @@ def test_trainer_loop_with_densification():
     assert float(model._denom.max()) <= 20                                 # statistics restarted at iteration 100
     assert losses[3] < 0.5 * first and np.isfinite(float(trainer.evaluate()))
     assert trainer.get_image_scale(0) == 0.25 and trainer.get_image_scale(300) == 0.5 and trainer.get_image_scale(900) == 1
+
+
+@pytest.mark.parametrize("n", [4, 257, 1024, 1025, 50_000])
+def test_knn_dist2_matches_oracle(n):
+    import gsplat_amd  # noqa: F401
+    import train_oracle as to
+    from gsplat_amd import _lib
+    rng = np.random.default_rng(n)
+    p = (rng.normal(size=(n, 3)) * np.array([3.0, 1.0, 0.3])).astype(np.float32)
+    if n > 100:
+        p[5] = p[6] = p[7] = p[8]                # coincident points: distance zero, own index skipped
+        p[n - 1] = p[0]                          # a duplicate in another tile of the search
+    pts = torch.from_numpy(p).to(dev())
+    out = torch.full((n,), -1.0, device=dev())
+    lib = _lib.load()
+    _lib.check(lib.gsr_knn_dist2(n, pts.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream), "knn")
+    want = to.knn_dist2(p)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-6 * float(want.max()))
+    if n > 100:
+        assert float(out[5]) == 0.0
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.gsr_knn_dist2(3, pts.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream), "knn")
+
+
+def test_from_pcd_matches_oracle_and_renders():
+    """GaussianModel.from_pcd (GaussianModel.py:71-97) from a coloured point cloud, then one render."""
+    import types
+    import gsplat_amd  # noqa: F401
+    import train_oracle as to
+    from gsplat_amd.model import GaussianModel
+    from gsplat_amd.renderer import GaussianRenderer
+    from gsplat_amd.scenes import synthetic_scene
+    sc = synthetic_scene(5000, 96, 64, 0, seed=4)
+    rng = np.random.default_rng(1)
+    pcd = types.SimpleNamespace(coords=sc.coords.numpy(), colors=rng.integers(0, 256, size=(5000, 3)).astype(np.uint8), size=5000)
+    m = GaussianModel.from_pcd(pcd, device=dev())
+    want = to.from_pcd(pcd.coords, pcd.colors)
+    assert m._size == 5000 and m.capacity == 5000 and m.sh_degree == 0 and m._sh.shape == (5000, 3, 16)
+    for k in KEYS:
+        np.testing.assert_allclose(getattr(m, "_" + k).detach().cpu().numpy(), want[k], rtol=RTOL, atol=1e-6, err_msg=k)
+    assert m._coords_grads.shape == (5000, 1) and m._denom.dtype == torch.int32
+    img, mask, _, radius = GaussianRenderer(m)(sc.camera(device=dev()), 16)
+    assert img is not None and torch.isfinite(img).all() and int(mask.sum()) == radius.shape[0] > 0

@@ -92,3 +92,17 @@ def test_remove_of_more_than_half_raises():
     m = load_model(d, "in_")
     with pytest.raises(RuntimeError):
         to.remove(m, np.ones(m["size"], bool))
+
+
+def test_knn_oracle_against_exhaustive_search():
+    """The k-d tree restatement of simple_knn's distCUDA2 against a plain O(N^2) search, with duplicates."""
+    rng = np.random.default_rng(5)
+    p = rng.normal(size=(300, 3)).astype(np.float32)
+    p[10] = p[11] = p[12] = p[13]                 # four coincident points: three neighbours at distance zero
+    p[20] = p[21]
+    got = to.knn_dist2(p)
+    d2 = ((p[:, None, :].astype(np.float64) - p[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)                   # the point's own index is skipped, nothing else
+    want = np.sort(d2, axis=1)[:, :3].mean(axis=1)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-12)
+    assert got[10] == 0.0 and got[20] > 0.0
