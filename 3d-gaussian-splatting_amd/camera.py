@@ -78,6 +78,18 @@ class Camera:
         self.world2model_matrix = torch.from_numpy(self.w2m_host).to(device=device, dtype=torch.float32)
         self.projection_matrix = torch.from_numpy(self.proj_host).to(device=device, dtype=torch.float32)
 
+    @staticmethod
+    def from_sfm(sfm_image, sfm_camera, width, height, device=None) -> "Camera":
+        """``Camera.from_sfm`` (``Utils/Camera.py:30-46``): a camera from a structure-from-motion pose.
+        ``sfm_image`` and ``sfm_camera`` are read through the attributes the reference reads of
+        ``pycolmap.Image`` / ``pycolmap.Camera`` (``cam_from_world.rotation.quat`` in x, y, z, w order,
+        ``projection_center()``, ``focal_length_x/y``, ``principal_point_x/y``); no SfM package is
+        imported here.  The quaternion is rolled to w, x, y, z and conjugated, as the reference does."""
+        rotation = np.roll(np.asarray(sfm_image.cam_from_world.rotation.quat, dtype=np.float64), 1)
+        rotation[1:] = -rotation[1:]
+        return Camera(sfm_image.projection_center(), rotation, sfm_camera.focal_length_x, sfm_camera.focal_length_y,
+                      sfm_camera.principal_point_x, sfm_camera.principal_point_y, width, height, device=device)
+
     def get_projection_matrix(self, near: float = 0.1, far: float = 100) -> np.ndarray:
         fov_x = 2 * math.atan(self.width / (2 * self.fx))
         fov_y = 2 * math.atan(self.height / (2 * self.fy))
@@ -109,3 +121,18 @@ def camera_constants(cam):
     # GaussianRenderer.py:73 casts the camera position to float32 before the subtraction.
     pos = np.ascontiguousarray(np.asarray(cam.transform.position), dtype=np.float32).reshape(3)
     return w2m, proj, pos
+
+
+def compute_scene_radius(translations) -> np.ndarray:
+    """``DataLoader.compute_scene_radius`` (``Utils/DataLoader.py:91-106``): per axis, the largest distance of
+    a registered image's ``cam_from_world.translation`` from the mean of those translations.  Returns the
+    three extents (the trainer uses their maximum, ``Trainer.py:33``)."""
+    t = np.asarray(translations, dtype=np.float32).reshape(-1, 3)
+    mean = np.zeros(3, dtype=np.float32)
+    for row in t:                     # accumulated in fp32 in image order, as the reference does
+        mean += row
+    mean /= len(t)
+    radius = np.zeros(3, dtype=np.float32)
+    for row in t:
+        radius = np.maximum(radius, np.abs(row - mean))
+    return radius

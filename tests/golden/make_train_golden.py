@@ -187,9 +187,35 @@ def make_remove(GM):
         save(name, **out)
 
 
+def make_camera(RefCamera):
+    """Camera.from_sfm (Utils/Camera.py:30-46) on stand-ins for pycolmap's Image and Camera that carry the
+    attributes the reference reads; the reference's own matrices are the expected output."""
+    import types
+    rng = np.random.default_rng(77)
+    out = {"cases": np.int64(5)}
+    for k in range(5):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)                                   # x, y, z, w
+        center = rng.normal(size=3) * 3
+        fx, fy = 500 + 300 * rng.random(), 480 + 300 * rng.random()
+        w, h = int(rng.integers(100, 900)), int(rng.integers(100, 900))
+        cx, cy = w / 2 + rng.normal(), h / 2 + rng.normal()
+        image = types.SimpleNamespace(cam_from_world=types.SimpleNamespace(rotation=types.SimpleNamespace(quat=q.copy())),
+                                      projection_center=lambda c=center: c.copy())
+        cam_model = types.SimpleNamespace(focal_length_x=fx, focal_length_y=fy, principal_point_x=cx, principal_point_y=cy)
+        cam = RefCamera.from_sfm(image, cam_model, w, h)
+        out[f"quat_xyzw_{k}"], out[f"center_{k}"] = q, center
+        out[f"intrinsics_{k}"] = np.array([fx, fy, cx, cy, w, h], np.float64)
+        out[f"w2m_{k}"] = cam.world2model_matrix.numpy().copy()
+        out[f"proj_{k}"] = cam.projection_matrix.numpy().copy()
+        out[f"position_{k}"] = np.asarray(cam.transform.position, np.float64)
+    save("camera_from_sfm", **out)
+
+
 def main():
     assert ref_harness.reference_available(), "needs /root/reference"
-    GM, _, _, _ = ref_harness._import_reference()
+    GM, _, RefCamera, _ = ref_harness._import_reference()
+    make_camera(RefCamera)
     make_adam()
     make_stats(GM)
     make_densify(GM)
