@@ -139,6 +139,13 @@ def remove(model, mask: torch.Tensor, inplace: bool = True):
     if size == 0:
         return 0
     dev = model._coords.device
+    if mask.dim() != 1:
+        # Trainer.py:68 hands over a mask broadcast to [N,M]; the reference returns at once when nothing
+        # is set in it (GaussianModel.py:149-151) and fails on the indexing otherwise
+        if not bool(mask.any()):
+            return 0
+        raise IndexError(f"remove: the mask has shape {tuple(mask.shape)}; a set entry of a mask that is not [size] cannot be "
+                         "applied (the reference fails on its boolean indexing here)")
     stream = _stream(dev)
     m8 = _mask_u8(mask, size)
     rank = torch.empty(size, dtype=torch.int32, device=dev)

@@ -48,9 +48,18 @@ class GaussianModel(GaussianParams):
     GPU: capacity rows of which ``_size`` are live, the densification statistics and the methods the
     trainer calls around a render (``Trainer.py:60-74``).  Each method does what the reference's
     method of the same name does, through the kernels behind ``densify.py`` (PLY I/O: ``ply.py``).
-    Point-cloud construction is not part of it."""
+    ``GaussianModel()`` / ``GaussianModel(max_sh_degree)`` is the reference's constructor: an empty model, to
+    be filled by ``load_ply`` (``main.py:31-32``)."""
 
-    def __init__(self, coords, scale, rotation, opacity, sh, sh_degree: int = 0, max_sh_degree: int = 3, size=None):
+    def __init__(self, coords=None, scale=None, rotation=None, opacity=None, sh=None, sh_degree: int = 0,
+                 max_sh_degree: int = 3, size=None):
+        if coords is None or isinstance(coords, int):
+            if isinstance(coords, int):
+                max_sh_degree = coords
+            dev = "cuda" if torch.cuda.is_available() else "cpu"
+            f32 = dict(dtype=torch.float32, device=dev)
+            coords, scale, rotation = torch.empty((0, 3), **f32), torch.empty((0, 3), **f32), torch.empty((0, 4), **f32)
+            opacity, sh = torch.empty((0, 1), **f32), torch.empty((0, 3, (max_sh_degree + 1) ** 2), **f32)
         super().__init__(coords, scale, rotation, opacity, sh, sh_degree, max_sh_degree)
         cap = coords.shape[0]
         self._size = cap if size is None else int(size)
@@ -103,6 +112,35 @@ class GaussianModel(GaussianParams):
     @property
     def sh(self):
         return self._sh[:self._size, :, :(self.curr_sh_degree + 1) ** 2]
+
+    @property
+    def covariance(self):
+        return self.get_covariance()
+
+    def get_covariance(self, mask: torch.Tensor = None):
+        """``GaussianModel.get_covariance`` (``GaussianModel.py:99-108``): ``(R S)(R S)^T`` per Gaussian, in
+        plain tensor operations (the renderer computes it inside its first kernel; this is for callers
+        such as ``Trainer.test``)."""
+        q, s = self.rotation, self.scale
+        if mask is not None:
+            q, s = q[mask], s[mask]
+        w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack((2 * (w * w + x * x) - 1, 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 2 * (w * w + y * y) - 1, 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 2 * (w * w + z * z) - 1), dim=1).reshape(-1, 3, 3)
+        RS = R * s[:, None, :]
+        return torch.bmm(RS, RS.transpose(1, 2))
+
+    def construct_list_of_attributes(self):
+        """``GaussianModel.py:256-266``."""
+        from . import ply
+        return ply.attribute_names(self._sh.shape[1] * self._sh.shape[2], self._scale.shape[1], self._rotation.shape[1])
+
+    def debug_memory(self):
+        """``GaussianModel.py:247-254``."""
+        for name in ("coords", "opacity", "scale", "rotation", "sh", "coords_grads", "denom"):
+            t = getattr(self, "_" + name)
+            print(f"{name} takes memory {t.element_size() * t.nelement()}")
 
     def reset_opacity(self):
         from . import densify as D

@@ -1,0 +1,61 @@
+"""CPU: the drop-in GaussianModel module (dropin/GaussianModel.py) - what main.py and Trainer.py use of the
+reference's class that needs no GPU: the reference's constructor forms, the activated properties, the
+3-D covariance against the reference's own (fixture), the all-false broadcast remove mask of
+Trainer.py:68."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util import load_golden  # noqa: E402
+
+
+def dropin_class():
+    path = os.path.join(ROOT, "3d-gaussian-splatting_amd", "dropin")
+    sys.path.insert(0, path)
+    try:
+        sys.modules.pop("GaussianModel", None)
+        from GaussianModel import GaussianModel
+    finally:
+        sys.path.remove(path)
+        sys.modules.pop("GaussianModel", None)
+    return GaussianModel
+
+
+def test_reference_constructor_forms():
+    GaussianModel = dropin_class()
+    m = GaussianModel()                      # main.py:31
+    assert m._size == 0 and m.capacity == 0 and m.max_sh_degree == 3 and m.curr_sh_degree == 0
+    assert m._sh.shape == (0, 3, 16) and len(list(m.parameters())) == 5
+    assert GaussianModel(2)._sh.shape == (0, 3, 9) and GaussianModel(max_sh_degree=1).max_sh_degree == 1
+    assert len(m.construct_list_of_attributes()) == 62
+
+
+def test_covariance_and_properties_match_the_reference():
+    GaussianModel = dropin_class()
+    g = load_golden("syn_n256_64x48_deg1_t64")
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k]))  # noqa: E731
+    m = GaussianModel(t("coords"), t("scale"), t("rotation"), t("opacity").reshape(-1, 1), t("sh"), sh_degree=int(g["sh_degree"]))
+    np.testing.assert_allclose(m.covariance.detach().numpy(), g["ref_cov3d"], rtol=1e-5, atol=1e-7)
+    mask = torch.from_numpy(g["ref_mask"])
+    np.testing.assert_allclose(m.get_covariance(mask).detach().numpy(), g["ref_cov3d"][g["ref_mask"]], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(m.opacity.detach().numpy()[g["ref_mask"]].reshape(-1), g["ref_opacity_act"].reshape(-1), rtol=1e-6)
+    assert m.sh.shape == (256, 3, 4) and m.size == 256 and m.sh_degree == 1
+    np.testing.assert_allclose(m.rotation.detach().norm(dim=1).numpy(), 1.0, rtol=1e-6)
+
+
+def test_broadcast_remove_mask_of_the_reference_trainer():
+    GaussianModel = dropin_class()
+    g = torch.Generator().manual_seed(0)
+    m = GaussianModel(torch.randn(6, 3, generator=g), torch.randn(6, 3, generator=g), torch.randn(6, 4, generator=g),
+                      torch.randn(6, 1, generator=g) + 5.0, torch.randn(6, 3, 16, generator=g))
+    radius = torch.rand(4) * 10
+    remove_mask = (m.opacity < 0.005) & (radius > 1000)          # Trainer.py:68: [N,1] & [M] -> [N,M]
+    assert remove_mask.shape == (6, 4) and m.remove(remove_mask) == 0 and m._size == 6
+    with pytest.raises(IndexError):
+        m.remove(torch.ones(6, 4, dtype=torch.bool))

@@ -374,3 +374,60 @@ def test_from_pcd_matches_oracle_and_renders():
     assert m._coords_grads.shape == (5000, 1) and m._denom.dtype == torch.int32
     img, mask, _, radius = GaussianRenderer(m)(sc.camera(device=dev()), 16)
     assert img is not None and torch.isfinite(img).all() and int(mask.sum()) == radius.shape[0] > 0
+
+
+def test_dropin_model_under_the_reference_trainer_statements():
+    """The statements of the reference's main.py and Trainer.train on the drop-in modules
+    (`from GaussianModel import GaussianModel`, `from GaussianRenderer import GaussianRenderer`),
+    with torch's own Adam as Trainer.py:24 builds it: from_pcd, render, backward, statistics,
+    add_sh_degree, densify, the broadcast remove mask, step, save_ply / load_ply."""
+    import types
+    import torch.optim as optim
+    path = os.path.join(ROOT, "3d-gaussian-splatting_amd", "dropin")
+    sys.path.insert(0, path)
+    try:
+        for name in ("GaussianModel", "GaussianRenderer"):
+            sys.modules.pop(name, None)
+        from GaussianModel import GaussianModel
+        from GaussianRenderer import GaussianRenderer
+    finally:
+        sys.path.remove(path)
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.loss import l1_loss, ssim_loss
+    from gsplat_amd.scenes import synthetic_scene
+    sc = synthetic_scene(3000, 96, 64, 0, seed=6)
+    rng = np.random.default_rng(0)
+    pcd = types.SimpleNamespace(coords=sc.coords.numpy(), colors=rng.integers(0, 256, size=(3000, 3)).astype(np.uint8), size=3000)
+    model = GaussianModel.from_pcd(pcd)                                     # main.py:29
+    optimizer = optim.Adam(model.parameters(), lr=1e-3, betas=(0.5, 0.999))  # Trainer.py:24
+    renderer = GaussianRenderer(model, False)                               # Trainer.py:32
+    assert str(renderer.device).startswith("cuda")
+    scene_radius = torch.tensor([0.5, 0.2, 0.1], device=renderer.device).max()   # Trainer.py:33
+    cam = sc.camera(device=dev())
+    target = torch.rand(96, 64, 3, device=dev()) * 255
+    for train_step in (49, 50):
+        optimizer.zero_grad(set_to_none=True)
+        rendered_image, visible_mask, screen_coords, radius = renderer(cam)      # default tile edge 64
+        assert rendered_image.requires_grad
+        loss = 0.8 * l1_loss(rendered_image, target) + 0.2 * (1 - ssim_loss(rendered_image, target))   # Trainer.py:36-38
+        loss.backward()
+        with torch.no_grad():
+            model.update_densify_stats(screen_coords, visible_mask)
+            if train_step % 50 == 0:
+                model.add_sh_degree()
+                size = model._size
+                model.densify(scene_radius)
+                remove_mask = (model.opacity < 0.005) & (radius > 1000)       # Trainer.py:68
+                model.remove(remove_mask)
+                assert model._size >= size and model.sh_degree == 1
+        optimizer.step()
+    file = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dropin_model_{os.getpid()}.ply")
+    try:
+        model.save_ply(file)                                                 # main.py:39
+        again = GaussianModel()
+        again.load_ply(file)                                                 # main.py:31-32
+    finally:
+        if os.path.exists(file):
+            os.remove(file)
+    assert again._size == model.capacity and torch.equal(again._coords.detach(), model._coords.detach())
+    assert again._coords.is_cuda and renderer.__class__(again)(cam)[0] is not None
