@@ -59,6 +59,29 @@ def accumulate_stats(model, g_screen: torch.Tensor, mask: torch.Tensor):
 
 
 @torch.no_grad()
+def stats_delta(size: int, g_screens, masks):
+    """What ``update_densify_stats`` would add for several views, as tensors of their own:
+    ``(grads [size,1] f32, denom [size,1] i32)`` starting from zero.  For ranks that each render a part
+    of a step's views: the deltas are summed over the ranks (``minibatch.reduce_densify_stats``) and
+    added to every rank's statistics."""
+    if len(g_screens) != len(masks):
+        raise ValueError(f"{len(g_screens)} gradients for {len(masks)} masks")
+    if not g_screens:
+        raise ValueError("stats_delta needs at least one view (the device is taken from it)")
+    dev = g_screens[0].device
+    grads = torch.zeros((size, 1), dtype=torch.float32, device=dev)
+    denom = torch.zeros((size, 1), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    for g, mask in zip(g_screens, masks):
+        if tuple(g.shape) != (size, 3) or not g.is_cuda or g.dtype != torch.float32:
+            raise ValueError(f"g_screen has shape {tuple(g.shape)}, expected float32 [{size},3] on the GPU")
+        m8 = _mask_u8(mask, size)
+        _call("gsr_densify_stats", lib.gsr_densify_stats, size, m8.data_ptr(), g.contiguous().data_ptr(),
+              grads.data_ptr(), denom.data_ptr(), _stream(dev))
+    return grads, denom
+
+
+@torch.no_grad()
 def expand_capacity(model, new_capacity: int):
     """``GaussianModel.expand_capacity`` (``GaussianModel.py:116-140``): zero rows appended, the
     parameters re-created as new ``nn.Parameter`` objects."""

@@ -1,8 +1,11 @@
 """View-minibatch data parallelism: the views of one optimisation step are independent renders, so
 they are split over the ranks; every rank accumulates the parameter gradients of its views in one
-flat fp32 bucket and the buckets are summed with a single all-reduce (RCCL over xGMI on the GPUs,
-gloo in the CPU tests).  The reference renders one view per step on one device (``Trainer.py:54-57``);
-this module is what carries that step to N GPUs.
+flat fp32 bucket and the ranks exchange them (RCCL over xGMI on the GPUs, gloo in the CPU tests):
+``reduce_gradients`` sums the 11 small floats per Gaussian and rebuilds the sh gradient from gathered
+colour gradients, ``GradBucket.all_reduce`` sums the whole bucket, ``reduce_densify_stats`` sums the
+densification statistics of the step's views.  The reference renders one view per step on one device
+(``Trainer.py:54-57``); this module is what carries that step to N GPUs (``trainer.MinibatchTrainer``
+is the training loop on top of it).
 """
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -166,18 +169,45 @@ def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: 
     identical to a single-rank run.  ``force_collectives`` issues the two collectives for a single
     rank too (a rehearsal of the multi-rank path).  Returns the gathered colour gradients."""
     import torch.distributed as dist
-    n = bucket.n
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     if not can_factor(n_views, world):
         raise ValueError(f"{n_views} views do not split evenly over {world} ranks")
     per_rank = n_views // world
-    if tuple(g_colors_local.shape) != (per_rank, n, 3) or not g_colors_local.is_contiguous():
-        raise ValueError(f"g_colors_local has shape {tuple(g_colors_local.shape)}, expected a contiguous [{per_rank},{n},3]")
+    # the bucket may have more rows than there are live Gaussians (a model's capacity): its rows
+    # beyond the colour gradients' N hold zeros and take part in the sum
+    if (g_colors_local.dim() != 3 or g_colors_local.shape[0] != per_rank or g_colors_local.shape[1] > bucket.n
+            or g_colors_local.shape[2] != 3 or not g_colors_local.is_contiguous()):
+        raise ValueError(f"g_colors_local has shape {tuple(g_colors_local.shape)}, expected a contiguous "
+                         f"[{per_rank},N<={bucket.n},3]")
+    n = g_colors_local.shape[1]
     if world == 1 and not (force_collectives and dist.is_available() and dist.is_initialized()):
         g_all = g_colors_local
     else:
-        dist.all_reduce(bucket.flat[:n * SMALL_FLOATS], op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(bucket.flat[:bucket.n * SMALL_FLOATS], op=dist.ReduceOp.SUM, group=group)
         g_all = torch.empty((n_views, n, 3), dtype=g_colors_local.dtype, device=g_colors_local.device)
         dist.all_gather_into_tensor(g_all, g_colors_local, group=group)
     rebuild_sh(g_all)
     return g_all
+
+
+def reduce_densify_stats(model, delta_grads: torch.Tensor, delta_denom: torch.Tensor, group=None):
+    """Densification statistics of a step whose views are spread over ranks: ``delta_grads`` ``[size,1]``
+    f32 and ``delta_denom`` ``[size,1]`` i32 are what this rank's views add (``densify.stats_delta``); they
+    are summed over the ranks (two all-reduces, 8 bytes per Gaussian) and added to the model's
+    ``_coords_grads`` / ``_denom``, so every rank holds the statistics of ALL views of the step - what
+    ``GaussianModel.update_densify_stats`` (``GaussianModel.py:230-232``) called once per view on one
+    device leaves, up to the order of the float additions - and every rank then takes the same
+    densification decisions."""
+    import torch.distributed as dist
+    size = int(model._size)
+    if tuple(delta_grads.shape) != (size, 1) or tuple(delta_denom.shape) != (size, 1):
+        raise ValueError(f"the deltas have shapes {tuple(delta_grads.shape)} / {tuple(delta_denom.shape)}, expected [{size},1]")
+    if delta_grads.dtype != torch.float32 or delta_denom.dtype != torch.int32:
+        raise TypeError("delta_grads must be float32 and delta_denom int32")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(delta_grads, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(delta_denom, op=dist.ReduceOp.SUM, group=group)
+    with torch.no_grad():
+        model._coords_grads[:size] += delta_grads
+        model._denom[:size] += delta_denom
+    return model

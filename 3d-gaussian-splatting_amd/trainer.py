@@ -112,3 +112,134 @@ class Trainer:
         if image is None:
             return None
         return float(self.compute_loss(image, target_image))
+
+
+class MinibatchTrainer(Trainer):
+    """``Trainer`` with an optimisation step over ``views_per_step`` views that are split over the ranks
+    of a ``torch.distributed`` process group (one process per GPU, RCCL): the loss of a step is the mean
+    of the views' training losses.  The reference trains on one view per step on one device
+    (``Trainer.py:54-57``); with ``views_per_step=1`` and one rank this is that loop.
+
+    Every rank holds the whole model and must draw the SAME views: ``dataloader.sample`` is called
+    ``views_per_step`` times per step on every rank (give the ranks equally seeded loaders) and a rank
+    renders the block ``minibatch.shard_views`` assigns to it.  Per step the ranks exchange the
+    parameter gradients (``minibatch.reduce_gradients``, or one all-reduce of the bucket when the
+    views do not split evenly), the densification statistics of their views
+    (``minibatch.reduce_densify_stats``) and, on the steps that remove Gaussians, the largest screen
+    radius of every Gaussian over the step's views (the reference tests the radius in its one view,
+    ``Trainer.py:68``).  The split's random draws come from a generator seeded with ``seed`` and the step
+    number, so all ranks draw the same; parameters, optimiser state and sizes stay identical on all ranks
+    without ever being broadcast."""
+
+    def __init__(self, model, dataloader, views_per_step: int = 8, group=None, seed: int = 0, **kwargs):
+        super().__init__(model, dataloader, **kwargs)
+        if views_per_step < 1:
+            raise ValueError("views_per_step must be at least 1")
+        self.views_per_step = int(views_per_step)
+        self.group = group
+        self.seed = int(seed)
+        self._bucket = None
+        self._bucket_rows = 0
+
+    def _ranks(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group), dist.get_rank(self.group)
+        return 1, 0
+
+    def _gradient_bucket(self, size: int):
+        """A bucket of capacity rows (what Adam updates), of which the first ``size`` receive gradients."""
+        from .minibatch import GradBucket
+        cap = self.model.capacity
+        if self._bucket is None or self._bucket.n != cap:
+            self._bucket = GradBucket(cap, self.model._coords.device)
+        elif size < self._bucket_rows:
+            self._bucket.flat.zero_()          # rows that were live in the last step and are not any more
+        self._bucket_rows = size
+        return self._bucket
+
+    def train_step(self, train_step: int):
+        import torch.distributed as dist
+        from . import densify as D
+        from .loss import loss_and_grad
+        from .minibatch import can_factor, reduce_densify_stats, reduce_gradients, render_views, shard_views
+        from .rasterizer import ViewSpec, sh_grad_views
+        model, V = self.model, self.views_per_step
+        world, rank = self._ranks()
+        dev = model._coords.device
+        while True:
+            samples = [self.dataloader.sample(is_train=True) for _ in range(V)]
+            size = int(model._size)
+            specs = [ViewSpec.from_camera(cam, model.curr_sh_degree, self.tile_length) for cam, _ in samples]
+            mine = shard_views(V, world, rank)
+            params = [p.data[:size] for p in (model._coords, model._scale, model._rotation, model._opacity, model._sh)]
+            bucket = self._gradient_bucket(size)
+            grads = tuple(v[:size] for v in bucket.views)
+            factored = world > 1 and can_factor(V, world)
+            g_colors = torch.empty((len(mine), size, 3), dtype=torch.float32, device=dev) if factored else None
+            losses = []
+
+            def cotangent(i, st):
+                out, dpred = loss_and_grad(st.img, samples[mine[i]][1], self.loss_lambda, 1.0 / V)
+                losses.append(out[0])
+                return dpred
+
+            states, _, g_screens = render_views(params, [specs[v] for v in mine], cotangent, grads=grads, g_colors=g_colors)
+            live = [st for st in states if st.num_visible]
+            # the reference draws again when nothing is visible (Trainer.py:52-55): here, when no view of
+            # the step on any rank shows anything
+            seen = torch.tensor([float(len(live))], device=dev)
+            if world > 1:
+                dist.all_reduce(seen, group=self.group)
+            if float(seen) > 0:
+                break
+        loss = torch.stack(losses).sum() / V if losses else torch.zeros((), device=dev)
+        if world > 1:
+            if factored:
+                reduce_gradients(bucket, g_colors, V, lambda g_all: sh_grad_views(specs, params[0], params[4], list(g_all), grads[4]),
+                                 group=self.group)
+            else:
+                bucket.all_reduce(self.group)
+            dist.all_reduce(loss, group=self.group)
+
+        with torch.no_grad():
+            if world > 1:
+                if live:
+                    dg, dd = D.stats_delta(size, g_screens, [st.mask_u8 for st in live])
+                else:
+                    dg = torch.zeros((size, 1), dtype=torch.float32, device=dev)
+                    dd = torch.zeros((size, 1), dtype=torch.int32, device=dev)
+                reduce_densify_stats(model, dg, dd, group=self.group)
+            else:
+                for st, gs in zip(live, g_screens):
+                    D.accumulate_stats(model, gs, st.mask_u8)
+            if train_step > 0 and train_step % 500 == 0:
+                model.add_sh_degree()
+            grew = False
+            if train_step > 0 and train_step % 50 == 0:
+                capacity = model.capacity
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(self.seed * 1000003 + train_step)
+                model.densify(self.scene_radius, generator=gen)
+                size_threshold = 20 if train_step > 1500 else 1000
+                if model._size == size:
+                    radius_all = torch.zeros(size, dtype=torch.float32, device=dev)
+                    for st in live:
+                        torch.maximum(radius_all, st.radius_full * st.mask_u8, out=radius_all)
+                    if world > 1:
+                        dist.all_reduce(radius_all, op=dist.ReduceOp.MAX, group=self.group)
+                    model.remove((model.opacity[:, 0] < 0.005) & (radius_all > size_threshold))
+                grew = model.capacity != capacity
+            if train_step > 0 and train_step % 1500 == 0:
+                model.reset_opacity()
+            if train_step > 0 and train_step % 500 == 0:
+                self.evaluate(train_step)
+                if self.checkpoint_dir is not None and rank == 0:
+                    os.makedirs(self.checkpoint_dir, exist_ok=True)
+                    torch.save((model.capture(self.optimizer), train_step),
+                               os.path.join(self.checkpoint_dir, f"checkpoint{train_step}.pth"))
+        if grew:
+            self.optimizer.resize(model.parameters())
+        else:
+            self.optimizer.step(grads=bucket.views)
+        return loss.detach()

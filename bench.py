@@ -133,7 +133,8 @@ def main():
     stats = {}
     model = opt = None
     if args.train_iter:
-        from gsplat_amd.densify import accumulate_stats
+        from gsplat_amd.densify import accumulate_stats, stats_delta
+        from gsplat_amd.minibatch import reduce_densify_stats
         from gsplat_amd.model import GaussianModel
         from gsplat_amd.optimizer import Adam
         model = GaussianModel(*params, sh_degree=args.sh_degree)
@@ -161,11 +162,19 @@ def main():
                              lambda g_all: sh_grad_views(all_views, params[0], params[4], list(g_all), bucket.sh),
                              force_collectives=True)
         if opt is not None:
-            # (each rank gathers the statistics of its own views; a trainer sums them over the ranks
-            # before it densifies, every 50 iterations)
             live = [st for st in states if st.num_visible]
-            for st, gs in zip(live, g_screens):
-                accumulate_stats(model, gs, st.mask_u8)
+            if use_dist:
+                # the statistics of the rank's views, summed over the ranks: every rank ends with those of
+                # all views of the step (8 bytes per Gaussian exchanged)
+                if live:
+                    dg, dd = stats_delta(n, g_screens, [st.mask_u8 for st in live])
+                else:
+                    dg = torch.zeros((n, 1), dtype=torch.float32, device=dev)
+                    dd = torch.zeros((n, 1), dtype=torch.int32, device=dev)
+                reduce_densify_stats(model, dg, dd)
+            else:
+                for st, gs in zip(live, g_screens):
+                    accumulate_stats(model, gs, st.mask_u8)
             opt.step(grads=bucket.views)
 
     def sync():
@@ -239,9 +248,10 @@ def main():
                 "workload": f"{n} synthetic Gaussians, SH degree {args.sh_degree}, {args.width}x{args.height}, "
                             f"tile {args.tile}, {args.views}-view minibatch {'forward only' if args.forward_only else 'fwd+bwd'} split over {world} GPU(s), "
                             + ("RCCL all-reduce of 11N gradient floats + all-gather of 3N colour-gradient floats per view, sh gradient rebuilt on every rank"
-                               if world > 1 and not args.forward_only else "no collective")
+                               if use_dist and not args.forward_only else "no collective")
                             + (", dL/dimg from the training loss kernel" if args.with_loss else "")
-                            + (", densification statistics and fused Adam step" if args.train_iter else ""),
+                            + (", densification statistics" + (" (summed over the ranks)" if use_dist else "") + " and fused Adam step"
+                               if args.train_iter else ""),
                 "gaussians": n, "width": args.width, "height": args.height, "tile_length": args.tile,
                 "sh_degree": args.sh_degree, "views_per_step": args.views,
                 "visible": stats.get("m"), "pairs_per_view": pairs,

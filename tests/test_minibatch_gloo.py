@@ -139,4 +139,75 @@ def test_factored_exchange_needs_an_even_split():
     from gsplat_amd.minibatch import GradBucket, can_factor, reduce_gradients
     assert can_factor(8, 1) and can_factor(8, 8) and not can_factor(8, 3)
     with pytest.raises(ValueError):
-        reduce_gradients(GradBucket(5, "cpu"), torch.zeros(2, 4, 3), 2, lambda g: None)    # wrong Gaussian count
+        reduce_gradients(GradBucket(5, "cpu"), torch.zeros(2, 6, 3), 2, lambda g: None)    # more Gaussians than bucket rows
+    # a bucket of capacity rows takes the colour gradients of fewer live Gaussians
+    seen = []
+    reduce_gradients(GradBucket(5, "cpu"), torch.zeros(2, 4, 3), 2, seen.append)
+    assert tuple(seen[0].shape) == (2, 4, 3)
+
+
+class _Stats:
+    """The three attributes reduce_densify_stats touches of a GaussianModel (GaussianModel.py:19-27)."""
+
+    def __init__(self, cap, size):
+        self._size = size
+        self._coords_grads = torch.zeros(cap, 1)
+        self._denom = torch.zeros(cap, 1, dtype=torch.int32)
+
+
+def _stats_inputs(view, size):
+    gen = torch.Generator().manual_seed(4000 + view)
+    return torch.randn(size, 3, generator=gen) * 1e-3, torch.rand(size, generator=gen) < 0.6
+
+
+def _stats_delta_cpu(views, size):
+    """What densify.stats_delta computes on the GPU, from the numpy restatement of update_densify_stats."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import train_oracle as to
+    m = {"size": size, "coords_grads": np.zeros((size, 1), np.float32), "denom": np.zeros((size, 1), np.int32)}
+    for v in views:
+        g, mask = _stats_inputs(v, size)
+        m = to.densify_stats(m, g.numpy(), mask.numpy())
+    return torch.from_numpy(m["coords_grads"].copy()), torch.from_numpy(m["denom"].copy())
+
+
+def _stats_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.minibatch import reduce_densify_stats, shard_views
+    cap, size = 50, 41
+    model = _Stats(cap, size)
+    model._coords_grads[:] = 0.25            # what earlier steps left, identical on the ranks
+    model._denom[:] = 3
+    for step in range(2):
+        dg, dd = _stats_delta_cpu([10 * step + v for v in shard_views(N_VIEWS, world, rank)], size)
+        reduce_densify_stats(model, dg, dd)
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), model._coords_grads.numpy())
+    np.save(os.path.join(out_dir, f"d{rank}.npy"), model._denom.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_densify_stats_equal_the_single_process(tmp_path):
+    """reduce_densify_stats: after two steps of four views split over two ranks, both ranks hold the
+    statistics a single process gathers from all eight views; rows at and above the size are untouched."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.minibatch import reduce_densify_stats
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_stats_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    cap, size = 50, 41
+    dg, dd = _stats_delta_cpu([10 * step + v for step in range(2) for v in range(N_VIEWS)], size)
+    for r in range(2):
+        g = np.load(os.path.join(str(tmp_path), f"g{r}.npy"))
+        d = np.load(os.path.join(str(tmp_path), f"d{r}.npy"))
+        np.testing.assert_allclose(g[:size], 0.25 + dg.numpy(), rtol=1e-6)
+        np.testing.assert_array_equal(d[:size], 3 + dd.numpy())
+        assert (g[size:] == 0.25).all() and (d[size:] == 3).all()
+    assert int(dd.max()) >= 4
+    with pytest.raises(ValueError):
+        reduce_densify_stats(_Stats(cap, size), torch.zeros(cap, 1), torch.zeros(cap, 1, dtype=torch.int32))
+    with pytest.raises(TypeError):
+        reduce_densify_stats(_Stats(cap, size), torch.zeros(size, 1), torch.zeros(size, 1))
