@@ -88,8 +88,18 @@ def main():
     if args.train_iter:
         args.with_loss = True
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started without the launcher: run it as a child (this process has not touched the GPU) and
+        # leave with its exit code
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GSR_BENCH_FORCE_DIST=1 rehearses the multi-rank code path (process group, all-reduce, barrier,
     # max over ranks) with a single rank, e.g. under torchrun --nproc-per-node 1
