@@ -286,25 +286,31 @@ def main():
         if flops_bwd and not args.forward_only:
             out["roofline"]["valu_frac_algorithmic"] = round(flops_bwd / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cams[0], args)
+            out["cpu_baseline"] = cpu_baseline(scene, cams, args)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 
 
-def cpu_baseline(scene, cam, args):
-    """The CPU port (oracle/) on this host's cores: one view of the minibatch, forward + backward."""
+def cpu_baseline(scene, cams, args, budget_s=12.0):
+    """The CPU port (oracle/) on this host's cores: forward + backward of the minibatch's views, one after
+    the other, until the views are done or about ``budget_s`` seconds are spent (at least one view)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     threads = min(oracle.max_threads(), 16)
     cot = np.full((args.width, args.height, 3), 1.0 / args.views, np.float32)
     p = [t.numpy() for t in scene.params()]
+    done = 0
     t0 = time.perf_counter()
-    oracle.render(p[0], p[1], p[2], p[3], p[4], args.sh_degree, args.width, args.height, args.tile,
-                  cam.w2m_host, cam.proj_host, np.asarray(cam.transform.position, np.float32), dimg=cot, threads=threads)
+    for cam in cams:
+        oracle.render(p[0], p[1], p[2], p[3], p[4], args.sh_degree, args.width, args.height, args.tile,
+                      cam.w2m_host, cam.proj_host, np.asarray(cam.transform.position, np.float32), dimg=cot, threads=threads)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
     dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "renders/s", "cores": threads, "kind": "port",
-            "sample": f"1 of the {args.views} views, forward + backward, same scene and tile size ({dt:.1f} s)"}
+    return {"value": round(done / dt, 4), "unit": "renders/s", "cores": threads, "kind": "port",
+            "sample": f"{done} of the {args.views} views, forward + backward, same scene and tile size ({dt:.1f} s)"}
 
 
 if __name__ == "__main__":
