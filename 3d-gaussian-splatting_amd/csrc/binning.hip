@@ -301,7 +301,7 @@ extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint
     if (!in_first) { gsr_set_error("gsr_bin_offsets: unexpected number of sort passes"); return GSR_ERR_LAUNCH; }
     // slot_base[order[s]] = sum over s' < s of ntiles[order[s']]
     if (int e = gsr_exclusive_scan_along(ntiles, order, slot_base, n, &counters->num_pairs, scan_ws, scan_bytes, stream,
-                                         slot_seq))
+                                         slot_seq, &counters->error))
         return e;
     return gsr_check_launch("bin_offsets");
 }

@@ -51,14 +51,31 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t x, uint32_t *lds, uint3
 // (a scan along a permutation; in and out may then not alias).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t *__restrict__ in,
                                                                    const uint32_t *__restrict__ idx, uint32_t n,
-                                                                   uint32_t *__restrict__ block_sums)
+                                                                   uint32_t *__restrict__ block_sums,
+                                                                   uint32_t *__restrict__ overflow_flag)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+    __shared__ unsigned long long wide;
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
+    unsigned long long s64 = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) s += in[idx ? idx[base + k] : base + k];
+        if (base + k < n) {
+            const uint32_t x = in[idx ? idx[base + k] : base + k];
+            s += x;
+            s64 += x;
+        }
+    if (overflow_flag) {
+        // the block's sum in 64 bits: a sum that does not fit 32 bits raises bit 1 of the flag word
+        if (threadIdx.x == 0) wide = 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s64 += __shfl_xor(s64, d, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&wide, s64);
+        __syncthreads();
+        if (threadIdx.x == 0 && (wide >> 32) != 0ull) atomicOr(overflow_flag, 2u);
+    }
     uint32_t total;
     block_exclusive_scan(s, lds, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -66,17 +83,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 
 // One block: exclusive scan of block_sums[0..nb) in place, total to *total_out (may be null).
 __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ block_sums, uint32_t nb,
-                                                         uint32_t *__restrict__ total_out)
+                                                         uint32_t *__restrict__ total_out,
+                                                         uint32_t *__restrict__ overflow_flag)
 {
     __shared__ uint32_t lds[1024 / 64 + 1];
+    __shared__ unsigned long long wide;
+    if (threadIdx.x == 0) wide = 0ull;
     uint32_t carry = 0;
+    unsigned long long mine = 0;
     for (uint32_t start = 0; start < nb; start += 1024) {
         const uint32_t i = start + threadIdx.x;
         const uint32_t x = i < nb ? block_sums[i] : 0u;
+        mine += x;
         uint32_t total;
         const uint32_t ex = block_exclusive_scan(x, lds, total);
         if (i < nb) block_sums[i] = carry + ex;
         carry += total;
+    }
+    if (overflow_flag) {
+        // the grand total in 64 bits (bit 1 of the flag word: it does not fit 32 bits)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) atomicAdd(&wide, mine);
+        __syncthreads();
+        if (threadIdx.x == 0 && (wide >> 32) != 0ull) atomicOr(overflow_flag, 2u);
     }
     if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
@@ -291,7 +322,8 @@ extern "C" size_t gsr_scan_workspace_bytes(uint32_t n)
 
 // library-internal: out[idx[i]] = sum over j < i of in[idx[j]]  (idx == null: the plain scan)
 int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
-                             void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq)
+                             void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq,
+                             uint32_t *overflow_flag)
 {
     hipStream_t st = (hipStream_t)stream;
     if (workspace_bytes < gsr_scan_workspace_bytes(n) || !workspace) {
@@ -307,8 +339,8 @@ int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *
     if (!in || !out) { gsr_set_error("gsr_exclusive_scan: null pointer"); return GSR_ERR_ARG; }
     uint32_t *sums = (uint32_t *)workspace;
     const uint32_t nb = gsr_div_up(n, SCAN_TILE);
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, n, sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb, total);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, n, sums, overflow_flag);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb, total, overflow_flag);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, out, n, sums, out_seq);
     return gsr_check_launch("exclusive_scan");
 }
@@ -316,7 +348,7 @@ int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *
 extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
-    return gsr_exclusive_scan_along(in, nullptr, out, n, total, workspace, workspace_bytes, stream, nullptr);
+    return gsr_exclusive_scan_along(in, nullptr, out, n, total, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)

@@ -201,6 +201,8 @@ def forward_lists(st: RenderState) -> RenderState:
     st._host = st._counters = st._ready = None
     if err & 1:
         raise SingularCovarianceError("singular 2-D covariance in a Gaussian that lands in a tile")
+    if err & 2:
+        raise RuntimeError("the view has more than 2^32 - 1 (tile, Gaussian) pairs: the per-tile lists cannot be indexed")
     if st.num_visible == 0:
         return st
     T = ((view.width + view.tile_length - 1) // view.tile_length) * ((view.height + view.tile_length - 1) // view.tile_length)

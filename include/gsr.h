@@ -48,7 +48,11 @@ typedef struct gsr_counters {
     uint32_t num_visible; /* M = mask.sum() */
     uint32_t num_pairs;   /* I = sum over tiles of list length */
     uint32_t error;       /* bit 0: a Gaussian that lands in a tile has a singular 2-D covariance
-                             (the reference raises in torch.linalg.inv, Utils/Probability.py:15) */
+                             (the reference raises in torch.linalg.inv, Utils/Probability.py:15);
+                             bit 1 (gsr_bin_offsets): the number of (tile, Gaussian) pairs does not fit
+                             32 bits - num_pairs and the slots are then meaningless and the caller must
+                             stop (the reference would build lists of that total length,
+                             GaussianRenderer.py:89-97) */
     uint32_t reserved[5];
 } gsr_counters;
 

@@ -62,3 +62,19 @@ def test_renderer_refuses_cpu_tensors():
     r = GaussianRenderer(GaussianParams.from_scene(sc, "cpu"))
     with pytest.raises(RuntimeError):
         r.render(sc.camera(device="cpu"), 16)
+
+
+def test_bin_lists_refuses_a_record_stream_of_4_gib():
+    """An argument check that runs before anything is launched: 2^26 pairs x 64 bytes reach the 32-bit
+    stream offsets the compositing kernels use."""
+    import ctypes as C
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd import _lib
+    lib = _lib.load()
+    view = _lib.make_view(10, 0, 3840, 2160, 16, [0.0] * 16, [0.0] * 16, [0.0] * 3)
+    dummy = (C.c_uint32 * 4)()
+    addr = C.addressof(dummy)
+    rc = lib.gsr_bin_lists(C.byref(view), addr, addr, addr, addr, addr, addr, 1 << 26, addr, None, addr, addr, addr, 1 << 40, None)
+    assert rc == -1          # GSR_ERR_ARG
+    with pytest.raises(RuntimeError, match="4 GiB"):
+        _lib.check(rc, "bin_lists")

@@ -80,3 +80,30 @@ def test_tile_order_is_a_permutation_by_descending_length(w, h, tile, kind):
     slack = int(lens.max()) // 1023 + 1
     assert (got[:-1] + slack >= got[1:]).all()
     assert got[0] + slack >= lens.max()
+
+
+@pytest.mark.parametrize("n,per,expect", [(70_000, 65_536, True),      # total 4.6e9: over 32 bits across blocks
+                                          (3_000, 2_000_000, True),    # 6e9 inside one block of the scan
+                                          (65_535, 65_536, False),     # 4 294 901 760: just fits
+                                          (1_000_000, 5, False)])
+def test_bin_offsets_flags_a_pair_count_beyond_32_bits(n, per, expect):
+    """gsr_bin_offsets sums the per-Gaussian tile counts; a total that does not fit 32 bits raises bit 1 of
+    the error word (the host then refuses to build lists), a total that fits leaves it alone."""
+    L, lib = _lib()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(n)
+    depth = torch.randint(0, 2**31 - 1, (n,), generator=gen, dtype=torch.int32).to(dev)
+    ntiles = torch.full((n,), per, dtype=torch.int32, device=dev)
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    slot_base = torch.empty(n, dtype=torch.int32, device=dev)
+    slot_seq = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    counters = torch.zeros(8, dtype=torch.int32, device=dev)
+    wsb = int(lib.gsr_bin_offsets_workspace_bytes(n))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    L.check(lib.gsr_bin_offsets(depth.data_ptr(), ntiles.data_ptr(), n, order.data_ptr(), slot_base.data_ptr(),
+                                slot_seq.data_ptr(), counters.data_ptr(), ws.data_ptr(), wsb, _stream()), "bin_offsets")
+    c = counters.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert bool(c[2] & 2) == expect
+    assert c[2] & ~2 == 0
+    if not expect:
+        assert c[1] == n * per
