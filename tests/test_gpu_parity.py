@@ -113,6 +113,12 @@ def _scene_arrays(sc):
     ("adv", 8000, 250, 130, 1, 50),
     ("orbit", 3000, 160, 120, 3, 16),
     ("orbit", 3000, 160, 120, 3, 64),
+    # tile edges below one 16x16 block, above four blocks (whole-tile hint bits) and larger than the image
+    ("syn", 5000, 160, 120, 1, 8),
+    ("adv", 5000, 130, 70, 2, 5),
+    ("syn", 10000, 320, 200, 1, 100),
+    ("syn", 10000, 320, 200, 3, 128),
+    ("orbit", 3000, 160, 120, 2, 1000),
 ])
 def test_mid_size_vs_oracle(oracle_mod, kind, n, w, h, deg, tile):
     import gsplat_amd  # noqa: F401
