@@ -25,6 +25,22 @@ from gsplat_amd.scenes import (adversarial_scene, all_culled_scene, orbit_scene,
                                synthetic_scene)
 import ref_harness  # noqa: E402
 
+def nonfinite_scene():
+    """A synthetic scene in which a few Gaussians carry non-finite or degenerate raw parameters: NaN and
+    infinite coordinates (culled: every comparison with NaN is false, Utils/Camera.py:106-108), a zero and
+    a NaN quaternion (the latter is visible but gets a NaN radius and an empty box, Utils/Screen.py:33-36),
+    raw opacities of plus and minus infinity (sigmoid 1 and 0)."""
+    sc = synthetic_scene(512, 64, 48, 1, seed=21)
+    nan, inf = float("nan"), float("inf")
+    sc.coords[3] = nan
+    sc.coords[4, 0] = inf
+    sc.rotation[5] = 0.0
+    sc.rotation[6] = nan
+    sc.opacity[7] = inf
+    sc.opacity[8] = -inf
+    return sc
+
+
 # name -> (scene factory, tile_length)
 CASES = {
     "syn_n256_64x48_deg0_t16": (lambda: synthetic_scene(256, 64, 48, 0, seed=10), 16),
@@ -36,12 +52,16 @@ CASES = {
     "orbit_n512_100x100_deg3_t16": (lambda: orbit_scene(512, 100, 100, 3, view=1, n_views=8, seed=16), 16),
     "syn_n512_64x48_deg3_t10": (lambda: synthetic_scene(512, 64, 48, 3, seed=17), 10),
     "culled_n256_64x48_deg0_t16": (lambda: all_culled_scene(256, 64, 48, 0, seed=18), 16),
+    "nonfinite_n512_64x48_deg1_t16": (nonfinite_scene, 16),
 }
 
 
 def main():
     assert ref_harness.reference_available(), "needs /root/reference"
+    only = sys.argv[1:]
     for name, (factory, tile) in CASES.items():
+        if only and name not in only:
+            continue
         sc = factory()
         cot = torch.rand(sc.width, sc.height, 3, generator=torch.Generator().manual_seed(1234),
                          dtype=torch.float32).numpy()

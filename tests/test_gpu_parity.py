@@ -106,6 +106,20 @@ def _scene_arrays(sc):
                 cam_pos=np.asarray(sc.cam_position, np.float32))
 
 
+def test_nonfinite_parameters_against_the_reference():
+    """NaN / infinite coordinates, a zero and a NaN quaternion, raw opacities of plus and minus infinity:
+    the fixture generated from the reference, checked exactly as the oracle is checked against it."""
+    from test_oracle_golden import check_nonfinite
+    from util import nonfinite_golden_names
+    names = nonfinite_golden_names()
+    assert names
+    for name in names:
+        g = load_golden(name)
+        h = run_hip(g["coords"], g["scale"], g["rotation"], g["opacity"], g["sh"], g["sh_degree"], g["width"], g["height"],
+                    g["tile_length"], g["w2m"], g["proj"], g["cam_pos"], cot=g["cotangent"])
+        check_nonfinite(h, g)
+
+
 @pytest.mark.parametrize("kind,n,w,h,deg,tile", [
     ("syn", 20000, 320, 200, 3, 16),
     ("syn", 20000, 320, 200, 2, 64),

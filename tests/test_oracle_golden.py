@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from util import assert_bit_equal, assert_close, golden_names, load_golden, loss_golden_names
+from util import (assert_bit_equal, assert_close, assert_close_nan, golden_names, load_golden, loss_golden_names,
+                  nonfinite_golden_names)
 
 GRADS = ("g_coords", "g_scale", "g_rotation", "g_opacity", "g_sh", "g_screen")
 
@@ -97,3 +98,36 @@ def test_loss_fixture_coverage():
     assert any(s[0] == 1 for s in shapes)            # a single image column
     assert any(load_golden(n)["gt"].max() > 200 for n in names)   # 0..255 targets (Utils/DataLoader.py:83)
     assert any((load_golden(n)["pred"] == load_golden(n)["gt"]).mean() > 0.1 for n in names)   # ties
+
+
+def check_nonfinite(o, g):
+    """What holds for a fixture with NaN / infinite parameters (used by the GPU test as well): the discrete
+    results are those of the reference, floats agree NaN for NaN.  One documented difference: a CULLED
+    Gaussian whose coordinates are not finite gets a NaN coordinate gradient from the reference (autograd
+    divides its zero cotangent by the NaN clip-space w, Utils/Camera.py:86) and a zero one here."""
+    m = g["ref_mask"]
+    assert_bit_equal(o["mask"], m, "mask")
+    # a NaN radius: the reference's int() of the NaN box edges gives INT_MIN four times (no tile contains
+    # it, Utils/Screen.py:38-62), here the box is stored as empty; either way the Gaussian is in no list
+    nan_box = np.isnan(g["ref_radius"])
+    assert nan_box.any() and (g["ref_bbox"][nan_box] == np.iinfo(np.int32).min).all()
+    assert_bit_equal(o["bbox"][m][~nan_box], g["ref_bbox"][~nan_box], "bbox")
+    assert not np.isin(np.nonzero(m)[0][nan_box], o["tile_lists"]).any()
+    assert_bit_equal(o["tile_offsets"], g["ref_tile_offsets"], "tile_offsets")
+    assert_bit_equal(o["tile_lists"], g["ref_tile_lists"], "tile_lists")
+    assert_close_nan(o["pos2d"][m], g["ref_pos2d"], "pos2d", rtol=1e-6)
+    assert_close_nan(o["cov2d"][m], g["ref_cov2d"].reshape(-1, 4), "cov2d")
+    assert_close_nan(o["radius"], g["ref_radius"], "radius")
+    assert np.isfinite(g["ref_img"]).all()
+    assert_close(o["img"], g["ref_img"], "img")
+    dead = np.nonzero(~np.isfinite(g["coords"]).all(axis=1) & ~m)[0]
+    assert len(dead) >= 2 and np.isnan(g["ref_g_coords"][dead]).all() and not o["g_coords"][dead].any()
+    for k in GRADS:
+        assert_close_nan(o[k], g["ref_" + k], k, skip_rows=dead if k == "g_coords" else None)
+
+
+@pytest.mark.parametrize("name", nonfinite_golden_names())
+def test_oracle_matches_reference_on_nonfinite_parameters(oracle_mod, name):
+    g = load_golden(name)
+    assert (~np.isfinite(g["coords"])).any() and np.isnan(g["rotation"]).any() and np.isinf(g["opacity"]).any()
+    check_nonfinite(run_oracle(oracle_mod, g), g)

@@ -20,7 +20,29 @@ def _names():
 def golden_names():
     """Fixtures of the render path (tests/golden/make_golden.py)."""
     other = ("loss_", "adam_", "stats_", "densify_", "remove_", "camera_")   # fixtures of the loss and of the training-state updates
-    return [n for n in _names() if not n.startswith(other)]
+    return [n for n in _names() if not n.startswith(other) and not n.startswith("nonfinite_")]
+
+
+def nonfinite_golden_names():
+    """Render fixtures whose inputs hold NaN / infinite parameters (compared NaN for NaN)."""
+    return [n for n in _names() if n.startswith("nonfinite_")]
+
+
+def assert_close_nan(got, ref, name="", skip_rows=None, **kw):
+    """assert_close for arrays that may hold NaN: the NaN positions must coincide and the rest must be
+    close.  ``skip_rows``: rows (first axis) left out of the comparison."""
+    got = np.array(got, dtype=np.float64, copy=True)
+    ref = np.array(ref, dtype=np.float64, copy=True)
+    assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
+    if skip_rows is not None:
+        keep = np.ones(got.shape[0], bool)
+        keep[skip_rows] = False
+        got, ref = got[keep], ref[keep]
+    gn, rn = np.isnan(got), np.isnan(ref)
+    assert np.array_equal(gn, rn), f"{name}: NaN at {np.argwhere(gn != rn)[:5].tolist()} on one side only"
+    got[gn] = 0.0
+    ref[rn] = 0.0
+    assert_close(got, ref, name, **kw)
 
 
 def loss_golden_names():
