@@ -507,6 +507,11 @@ int gso_preprocess_bwd(const gso_view *v, const float *coords, const float *scal
                 for (int c = 0; c < 2; ++c) tmp[r][c] = C[0][r] * Gm[0][c] + C[1][r] * Gm[1][c]; /* C^T G */
             for (int r = 0; r < 2; ++r)
                 for (int c = 0; c < 2; ++c) D[r][c] = -(tmp[r][0] * C[c][0] + tmp[r][1] * C[c][1]); /* . C^T */
+            /* The reference inverts the covariances of the Gaussians of a tile's list only
+             * (GaussianRenderer.py:89-97, Utils/Probability.py:15): a Gaussian in no list receives an exact
+             * zero here even when its covariance is singular (a zero scale), not 0 * inf. */
+            if (Gm[0][0] == 0.0 && Gm[0][1] == 0.0 && Gm[1][0] == 0.0 && Gm[1][1] == 0.0)
+                D[0][0] = D[0][1] = D[1][0] = D[1][1] = 0.0;
         }
         /* cov2 = M S M^T, M = J W */
         double dS[3][3], dM[2][3];

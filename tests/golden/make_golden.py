@@ -29,7 +29,8 @@ def nonfinite_scene():
     """A synthetic scene in which a few Gaussians carry non-finite or degenerate raw parameters: NaN and
     infinite coordinates (culled: every comparison with NaN is false, Utils/Camera.py:106-108), a zero and
     a NaN quaternion (the latter is visible but gets a NaN radius and an empty box, Utils/Screen.py:33-36),
-    raw opacities of plus and minus infinity (sigmoid 1 and 0)."""
+    raw opacities of plus and minus infinity (sigmoid 1 and 0), raw scales of minus infinity and -60 (zero
+    extent: visible, in no list, and the reference never inverts their covariance)."""
     sc = synthetic_scene(512, 64, 48, 1, seed=21)
     nan, inf = float("nan"), float("inf")
     sc.coords[3] = nan
@@ -38,6 +39,8 @@ def nonfinite_scene():
     sc.rotation[6] = nan
     sc.opacity[7] = inf
     sc.opacity[8] = -inf
+    sc.scale[9] = -inf          # exp -> 0: a singular covariance, but the empty box keeps it out of every list
+    sc.scale[11] = -60.0        # the same with a covariance that underflows
     return sc
 
 
