@@ -107,6 +107,34 @@ class Camera:
             dtype=float,
         )
 
+    def get_covariance2d(self, pos, cov3d: torch.Tensor) -> torch.Tensor:
+        """``Camera.get_covariance2d`` (``Utils/Camera.py:74-87``): ``J W cov3d W^T J^T`` with the Jacobian
+        taken at the WORLD-space point, as the reference does.  ``pos``: ``[M,>=3]``; returns ``[M,2,2]``.
+        (The renderer computes the same inside its first kernel; this is for callers such as
+        ``Trainer.test``.)"""
+        x, y, z = pos[:, 0], pos[:, 1], pos[:, 2]
+        zero = torch.zeros_like(z)
+        jac = torch.stack((1 / z, zero, -x / z, zero, 1 / z, -y / z), dim=1).view(-1, 2, 3)
+        m = jac @ self.world2model_matrix.to(pos.device)[:3, :3].T
+        return m @ cov3d @ m.transpose(1, 2)
+
+    def project_gaussian(self, screen_coords: torch.Tensor, pos3d: torch.Tensor, cov3d: torch.Tensor, relax_factor: float = 1.3):
+        """``Camera.project_gaussian`` (``Utils/Camera.py:89-117``) in tensor operations: ``(pos2d [M,3] in
+        pixels with the NDC depth third, cov2d [M,2,2], mask [N])``, or ``(None, None, mask)`` when the mask
+        is empty."""
+        dev = pos3d.device
+        homo = torch.nn.functional.pad(pos3d, (0, 1), value=1.0)
+        clip = homo @ self.world2model_matrix.to(dev).T @ self.projection_matrix.to(dev).T
+        ndc = clip[:, :3] / clip[:, 3:4]
+        mask = (ndc[:, 2] >= 0.1) & (-relax_factor <= ndc[:, 0]) & (ndc[:, 0] <= relax_factor) \
+            & (-relax_factor <= ndc[:, 1]) & (ndc[:, 1] <= relax_factor)
+        if not bool(mask.any()):
+            return None, None, mask
+        shifted = screen_coords[mask] + ndc[mask]
+        pos2d = torch.stack((0.5 * (shifted[:, 0] + 1) * self.width, (1 - 0.5 * (shifted[:, 1] + 1)) * self.height,
+                             shifted[:, 2]), dim=1)
+        return pos2d, self.get_covariance2d(homo[mask], cov3d[mask]), mask
+
 
 def camera_constants(cam):
     """Return ``(w2m[16], proj[16], position[3])`` as contiguous float32 numpy

@@ -41,3 +41,35 @@ def test_scene_radius():
     assert r.dtype == np.float32 and r.shape == (3,)
     np.testing.assert_allclose(r, want, rtol=1e-5)
     np.testing.assert_array_equal(compute_scene_radius(t[:1]), np.zeros(3, np.float32))
+
+
+def test_project_gaussian_matches_the_reference_fixtures():
+    """Camera.project_gaussian and GaussianModel.covariance (Utils/Camera.py:74-117, GaussianModel.py:99-108,
+    the pair Trainer.test calls) against what the reference's render produced on the golden scenes."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    from util import golden_names, load_golden
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.camera import Camera
+    from gsplat_amd.model import GaussianModel
+    checked = 0
+    for name in golden_names():
+        g = load_golden(name)
+        t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k], dtype=np.float32))  # noqa: E731
+        model = GaussianModel(t("coords"), t("scale"), t("rotation"), t("opacity").reshape(-1, 1), t("sh"),
+                              sh_degree=int(g["sh_degree"]))
+        cam = Camera(np.zeros(3), np.array([1.0, 0, 0, 0]), 1.0, 1.0, 0.0, 0.0, int(g["width"]), int(g["height"]), device="cpu")
+        cam.world2model_matrix = torch.from_numpy(np.asarray(g["w2m"], np.float32).reshape(4, 4))
+        cam.projection_matrix = torch.from_numpy(np.asarray(g["proj"], np.float32).reshape(4, 4))
+        with torch.no_grad():        # Trainer.test runs under no_grad (Trainer.py:106)
+            pos2d, cov2d, mask = cam.project_gaussian(torch.zeros_like(model.coords), model.coords, model.covariance)
+        if not bool(g["visible"]):
+            assert pos2d is None and cov2d is None and not mask.any()
+            continue
+        assert np.array_equal(mask.numpy(), g["ref_mask"])
+        np.testing.assert_allclose(pos2d.numpy(), g["ref_pos2d"], rtol=1e-5, atol=1e-4)
+        ref = g["ref_cov2d"].reshape(-1, 2, 2)
+        np.testing.assert_allclose(cov2d.numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+        checked += 1
+    assert checked >= 8
