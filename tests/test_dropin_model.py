@@ -59,3 +59,28 @@ def test_broadcast_remove_mask_of_the_reference_trainer():
     assert remove_mask.shape == (6, 4) and m.remove(remove_mask) == 0 and m._size == 6
     with pytest.raises(IndexError):
         m.remove(torch.ones(6, 4, dtype=torch.bool))
+
+
+def test_utils_shim_overrides_the_loss_module_only(tmp_path):
+    """dropin/Utils: Utils.Loss is this package's, every other Utils module still the checkout's (here a
+    stand-in checkout with one module)."""
+    import subprocess
+    import sys
+    fake = tmp_path / "checkout"
+    (fake / "Utils").mkdir(parents=True)
+    (fake / "Utils" / "__init__.py").write_text("")
+    (fake / "Utils" / "ContainerUtils.py").write_text("def torch2numpy(t):\n    return 'from the checkout'\n")
+    (fake / "Utils" / "Loss.py").write_text("def l1_loss(a, b):\n    return 'from the checkout'\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dropin = os.path.join(root, "3d-gaussian-splatting_amd", "dropin")
+    code = (
+        "import sys\n"
+        f"sys.path[:0] = [{dropin!r}, {str(fake)!r}]\n"
+        "from Utils.ContainerUtils import torch2numpy\n"
+        "from Utils.Loss import l1_loss, ssim_loss\n"
+        "from GaussianRenderer import GaussianRenderer\n"
+        "from GaussianModel import GaussianModel\n"
+        "print(torch2numpy(None), l1_loss.__module__, ssim_loss.__module__, GaussianRenderer.__module__, GaussianModel.__module__)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split("\n")[0] == "from the checkout gsplat_amd.loss gsplat_amd.loss gsplat_amd.renderer gsplat_amd.model"

@@ -378,7 +378,8 @@ def test_from_pcd_matches_oracle_and_renders():
 
 def test_dropin_model_under_the_reference_trainer_statements():
     """The statements of the reference's main.py and Trainer.train on the drop-in modules
-    (`from GaussianModel import GaussianModel`, `from GaussianRenderer import GaussianRenderer`),
+    (`from GaussianModel import GaussianModel`, `from GaussianRenderer import GaussianRenderer`,
+    `from Utils.Loss import l1_loss, ssim_loss`),
     with torch's own Adam as Trainer.py:24 builds it: from_pcd, render, backward, statistics,
     add_sh_degree, densify, the broadcast remove mask, step, save_ply / load_ply."""
     import types
@@ -386,15 +387,18 @@ def test_dropin_model_under_the_reference_trainer_statements():
     path = os.path.join(ROOT, "3d-gaussian-splatting_amd", "dropin")
     sys.path.insert(0, path)
     try:
-        for name in ("GaussianModel", "GaussianRenderer"):
+        for name in ("GaussianModel", "GaussianRenderer", "Utils", "Utils.Loss"):
             sys.modules.pop(name, None)
         from GaussianModel import GaussianModel
         from GaussianRenderer import GaussianRenderer
+        from Utils.Loss import l1_loss, ssim_loss                           # Trainer.py:7
     finally:
         sys.path.remove(path)
+        for name in ("Utils", "Utils.Loss"):
+            sys.modules.pop(name, None)
     import gsplat_amd  # noqa: F401
-    from gsplat_amd.loss import l1_loss, ssim_loss
     from gsplat_amd.scenes import synthetic_scene
+    assert l1_loss.__module__ == "gsplat_amd.loss"
     sc = synthetic_scene(3000, 96, 64, 0, seed=6)
     rng = np.random.default_rng(0)
     pcd = types.SimpleNamespace(coords=sc.coords.numpy(), colors=rng.integers(0, 256, size=(3000, 3)).astype(np.uint8), size=3000)
