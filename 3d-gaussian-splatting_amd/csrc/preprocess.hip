@@ -441,6 +441,15 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     bool any = false;
     for (int vv = 0; vv < a.nv; ++vv) any |= a.mask[vv][i] != 0;
     if (!any) {
+        // Culled in every view: a zero cotangent, but the reference's autograd still divides it by the
+        // clip-space w and multiplies it by the clip coordinates (the backward of Utils/Camera.py:103), so
+        // coordinates that are not finite - which is why such a Gaussian is culled - give a NaN coordinate
+        // gradient there, and here.
+        {
+            const float c0 = coords[3 * i], c1 = coords[3 * i + 1], c2 = coords[3 * i + 2];
+            if (!(__builtin_isfinite(c0) && __builtin_isfinite(c1) && __builtin_isfinite(c2)))
+                gc[0] = gc[1] = gc[2] = __builtin_nanf("");
+        }
         for (int vv = 0; vv < a.nv; ++vv) {
             float *gsv = a.g_screen[vv] + 3 * (size_t)i;
             gsv[0] = 0.0f; gsv[1] = 0.0f; gsv[2] = 0.0f;

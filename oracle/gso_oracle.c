@@ -452,7 +452,14 @@ int gso_preprocess_bwd(const gso_view *v, const float *coords, const float *scal
         gc[0] = gc[1] = gc[2] = 0.f; gs[0] = gs[1] = gs[2] = 0.f; gr[0] = gr[1] = gr[2] = gr[3] = 0.f;
         gsc[0] = gsc[1] = gsc[2] = 0.f; g_opac[i] = 0.f;
         memset(g_sh + (size_t)i * 48, 0, 48 * sizeof(float));
-        if (!mask[i]) continue;
+        if (!mask[i]) {
+            /* A culled Gaussian has a zero cotangent, but the reference's autograd still divides it by the
+             * clip-space w and multiplies it by the clip coordinates (the backward of Utils/Camera.py:103):
+             * coordinates that are not finite turn its whole coordinate gradient into NaN. */
+            const float *pc = coords + 3 * i;
+            if (!(isfinite(pc[0]) && isfinite(pc[1]) && isfinite(pc[2]))) gc[0] = gc[1] = gc[2] = NAN;
+            continue;
+        }
         geom_t g;
         const float *p = coords + 3 * i;
         geometry(v, p, scale_raw + 3 * i, rot_raw + 4 * i, &g);
