@@ -293,6 +293,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 acc += 0.5f;
                 col[ch] = acc < 0.0f ? 0.0f : acc;
             }
+            // A NaN opacity makes alpha NaN in the reference (torch.clamp keeps NaN, GaussianRenderer.py:104)
+            // and with it every pixel of the Gaussian's tiles.  The compositing kernels clamp with min/max
+            // instructions, which drop a NaN operand, so the NaN is handed on through the colour instead:
+            // the image comes out NaN in the same pixels and a diverged model stays visible in the loss.
+            if (o != o) col[0] = col[1] = col[2] = o;
             r0 = make_float4(px, py, kk * ia, kk * (ib + ic));
             r1 = make_float4(kk * id, o, col[0], col[1]);
             r2 = make_float4(col[2], ia, 0.5f * (ib + ic), id);

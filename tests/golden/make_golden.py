@@ -44,6 +44,16 @@ def nonfinite_scene():
     return sc
 
 
+def nan_colour_scene():
+    """A NaN sh coefficient and a NaN raw opacity: the reference's image is NaN in every pixel of the tiles
+    those two Gaussians are listed in (each entry is blended into each pixel of its tile,
+    GaussianRenderer.py:104-112)."""
+    sc = synthetic_scene(256, 64, 48, 0, seed=22)
+    sc.sh[10, 0, 0] = float("nan")
+    sc.opacity[12] = float("nan")
+    return sc
+
+
 # name -> (scene factory, tile_length)
 CASES = {
     "syn_n256_64x48_deg0_t16": (lambda: synthetic_scene(256, 64, 48, 0, seed=10), 16),
@@ -56,6 +66,7 @@ CASES = {
     "syn_n512_64x48_deg3_t10": (lambda: synthetic_scene(512, 64, 48, 3, seed=17), 10),
     "culled_n256_64x48_deg0_t16": (lambda: all_culled_scene(256, 64, 48, 0, seed=18), 16),
     "nonfinite_n512_64x48_deg1_t16": (nonfinite_scene, 16),
+    "nancolour_n256_64x48_deg0_t16": (nan_colour_scene, 16),
 }
 
 

@@ -120,6 +120,20 @@ def test_nonfinite_parameters_against_the_reference():
         check_nonfinite(h, g)
 
 
+def test_nan_colour_and_opacity_spread_like_the_reference():
+    """A NaN sh coefficient and a NaN raw opacity turn the pixels of their tiles NaN, as in the reference's
+    image (fixture generated from it); nothing is silently clamped away."""
+    from test_oracle_golden import check_nan_colour
+    from util import nan_colour_golden_names
+    names = nan_colour_golden_names()
+    assert names
+    for name in names:
+        g = load_golden(name)
+        h = run_hip(g["coords"], g["scale"], g["rotation"], g["opacity"], g["sh"], g["sh_degree"], g["width"], g["height"],
+                    g["tile_length"], g["w2m"], g["proj"], g["cam_pos"], cot=g["cotangent"])
+        check_nan_colour(h, g)
+
+
 @pytest.mark.parametrize("kind,n,w,h,deg,tile", [
     ("syn", 20000, 320, 200, 3, 16),
     ("syn", 20000, 320, 200, 2, 64),

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from util import (assert_bit_equal, assert_close, assert_close_nan, golden_names, load_golden, loss_golden_names,
-                  nonfinite_golden_names)
+                  nan_colour_golden_names, nonfinite_golden_names)
 
 GRADS = ("g_coords", "g_scale", "g_rotation", "g_opacity", "g_sh", "g_screen")
 
@@ -131,3 +131,24 @@ def test_oracle_matches_reference_on_nonfinite_parameters(oracle_mod, name):
     g = load_golden(name)
     assert (~np.isfinite(g["coords"])).any() and np.isnan(g["rotation"]).any() and np.isinf(g["opacity"]).any()
     check_nonfinite(run_oracle(oracle_mod, g), g)
+
+
+def check_nan_colour(o, g):
+    """A NaN colour or opacity: lists as the reference's, the image NaN in exactly the reference's pixels
+    (whole tiles) and close elsewhere, and the gradients carry NaN too, so the loss shows the divergence.
+    (Which gradient elements are NaN depends on where a 0 * NaN happens to be skipped; not compared.)"""
+    m = g["ref_mask"]
+    assert_bit_equal(o["mask"], m, "mask")
+    assert_bit_equal(o["tile_offsets"], g["ref_tile_offsets"], "tile_offsets")
+    assert_bit_equal(o["tile_lists"], g["ref_tile_lists"], "tile_lists")
+    bad = np.isnan(g["ref_img"])
+    assert bad.any() and not bad.all() and bad.all(axis=2).any() and (bad.any(axis=2) & ~bad.all(axis=2)).any()
+    assert_close_nan(o["img"], g["ref_img"], "img")
+    assert np.isnan(o["g_opacity"]).any() and np.isnan(o["g_coords"]).any()
+
+
+@pytest.mark.parametrize("name", nan_colour_golden_names())
+def test_oracle_spreads_nan_like_the_reference(oracle_mod, name):
+    g = load_golden(name)
+    assert np.isnan(g["sh"]).any() and np.isnan(g["opacity"]).any()
+    check_nan_colour(run_oracle(oracle_mod, g), g)

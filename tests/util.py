@@ -20,7 +20,12 @@ def _names():
 def golden_names():
     """Fixtures of the render path (tests/golden/make_golden.py)."""
     other = ("loss_", "adam_", "stats_", "densify_", "remove_", "camera_")   # fixtures of the loss and of the training-state updates
-    return [n for n in _names() if not n.startswith(other) and not n.startswith("nonfinite_")]
+    return [n for n in _names() if not n.startswith(other) and not n.startswith(("nonfinite_", "nancolour_"))]
+
+
+def nan_colour_golden_names():
+    """Render fixtures in which a NaN colour or opacity spreads NaN over whole tiles of the image."""
+    return [n for n in _names() if n.startswith("nancolour_")]
 
 
 def nonfinite_golden_names():
