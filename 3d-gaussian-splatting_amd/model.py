@@ -1,9 +1,10 @@
-"""Minimal stand-in for the reference ``GaussianModel`` parameter container.
+"""The model containers.
 
-Holds exactly the attributes the renderer reads (``GaussianModel.py:19-26,42-69``): raw
-``nn.Parameter``s of capacity rows, ``_size`` live rows and ``curr_sh_degree``.  Used by tests and
-``bench.py`` on machines where the reference checkout is absent; the reference's own
-``GaussianModel`` works with the renderer unchanged.
+``GaussianParams`` holds exactly the attributes the renderer reads (``GaussianModel.py:19-26,42-69``):
+raw ``nn.Parameter``s of capacity rows, ``_size`` live rows and ``curr_sh_degree``.  ``GaussianModel``
+adds the reference class's training-state surface on the GPU (statistics, densification, removal,
+PLY files, ``from_pcd``).  The reference's own ``GaussianModel`` works with the renderer and with
+``densify.py`` unchanged.
 """
 import torch
 import torch.nn as nn
