@@ -151,6 +151,89 @@ def densify(model, scene_radius, noise: torch.Tensor = None, generator: torch.Ge
     return num_clone, num_split
 
 
+def _mask_ranks(mask: torch.Tensor, size: int):
+    """(flags u8, rank i32 = number of set rows below each row, count) of a ``[size]`` mask, the ranks by
+    ``gsr_exclusive_scan``; one read-back for the count, as the reference's ``mask.sum()``."""
+    lib = _lib.load()
+    flags = _mask_u8(mask, size)
+    dev = flags.device
+    if not flags.is_cuda:
+        raise RuntimeError("the mask must be on the GPU (there is no CPU path)")
+    wide = flags.to(torch.int32)
+    rank = torch.empty(size, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.gsr_scan_workspace_bytes(size)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _call("gsr_exclusive_scan", lib.gsr_exclusive_scan, wide.data_ptr(), rank.data_ptr(), size, total.data_ptr(), ws.data_ptr(),
+          ws_bytes, _stream(dev))
+    return flags, rank, int(total.cpu())
+
+
+def _grow_for(model, new_size: int, what: str):
+    """The capacity rule of ``clone`` and ``split`` (``GaussianModel.py:184-187,204-207``): doubled once when
+    the new size reaches it."""
+    if new_size >= model._coords.shape[0]:
+        expand_capacity(model, 2 * model._coords.shape[0])
+    if new_size > model._coords.shape[0]:
+        raise RuntimeError(f"{what}: the doubled capacity cannot hold the new rows (the reference fails here too)")
+
+
+@torch.no_grad()
+def clone(model, mask: torch.Tensor, expand_factor: int = 2):
+    """``GaussianModel.clone(mask)`` (``GaussianModel.py:179-197``) on its own: the masked rows are appended
+    after the live rows, the statistics zeroed.  ``expand_factor`` is accepted and, as in the reference,
+    not used (the capacity doubles).  Returns the number of cloned rows."""
+    lib = _lib.load()
+    size = int(model._size)
+    if size == 0:
+        return 0
+    flags, rank, num = _mask_ranks(mask, size)
+    if num == 0:
+        return 0                      # the statistics persist (GaussianModel.py:181-182)
+    _grow_for(model, size + num, "clone")
+    coords, scale, rot, opac, sh = _rows(model)
+    _call("gsr_densify_apply", lib.gsr_densify_apply, size, num, 0, flags.data_ptr(), rank.data_ptr(), rank.data_ptr(), None,
+          coords.data_ptr(), scale.data_ptr(), rot.data_ptr(), opac.data_ptr(), sh.data_ptr(), _stream(coords.device))
+    _zero_stats(model)
+    model._size = size + num
+    return num
+
+
+@torch.no_grad()
+def split(model, mask: torch.Tensor, expand_factor: int = 2, split_factor: int = 2, noise: torch.Tensor = None,
+          generator: torch.Generator = None):
+    """``GaussianModel.split(mask)`` (``GaussianModel.py:199-228``) on its own, for the reference's
+    ``split_factor`` of 2: every masked row is replaced by a sample around the origin of its own frame and a
+    second sample is appended, both with the scale divided by 1.6.  ``noise`` as in ``densify``.  Returns
+    the number of split rows."""
+    if split_factor != 2:
+        raise NotImplementedError("split_factor 2 only (the value every call of the reference uses)")
+    lib = _lib.load()
+    size = int(model._size)
+    if size == 0:
+        return 0
+    flags, rank, num = _mask_ranks(mask, size)
+    if num == 0:
+        return 0
+    _grow_for(model, size + num, "split")
+    dev = model._coords.device
+    if noise is None:
+        noise = torch.randn((2 * num, 3), dtype=torch.float32, device=dev, generator=generator)
+    if noise.dim() != 2 or noise.shape[1] != 3 or noise.shape[0] < 2 * num or noise.dtype != torch.float32:
+        raise ValueError(f"noise has shape {tuple(noise.shape)}, expected float32 [>= {2 * num}, 3]")
+    noise = noise.to(dev).contiguous()
+    if noise.shape[0] != 2 * num:
+        # the kernel reads the second sample of row k at noise[num_split + k]
+        noise = noise[:2 * num].contiguous()
+    cls = flags * 2                   # 2 = split (gsr_densify_select's encoding)
+    coords, scale, rot, opac, sh = _rows(model)
+    _call("gsr_densify_apply", lib.gsr_densify_apply, size, 0, num, cls.data_ptr(), rank.data_ptr(), rank.data_ptr(),
+          noise.data_ptr(), coords.data_ptr(), scale.data_ptr(), rot.data_ptr(), opac.data_ptr(), sh.data_ptr(), _stream(dev))
+    _zero_stats(model)
+    model._size = size + num
+    return num
+
+
 @torch.no_grad()
 def remove(model, mask: torch.Tensor, inplace: bool = True):
     """``GaussianModel.remove(mask, inplace=True)`` (``GaussianModel.py:148-164``) for a 1-D mask,

@@ -163,6 +163,14 @@ class GaussianModel(GaussianParams):
         from . import densify as D
         return D.densify(self, scene_radius, noise=noise, generator=generator)
 
+    def clone(self, mask, expand_factor: int = 2):
+        from . import densify as D
+        return D.clone(self, mask, expand_factor)
+
+    def split(self, mask, expand_factor: int = 2, split_factor: int = 2, noise=None, generator=None):
+        from . import densify as D
+        return D.split(self, mask, expand_factor, split_factor, noise=noise, generator=generator)
+
     def remove(self, mask, inplace: bool = True):
         from . import densify as D
         return D.remove(self, mask, inplace)

@@ -89,40 +89,35 @@ def normalize(q):
     return (q / np.maximum(nrm, F32(1e-12))).astype(F32)
 
 
-def densify(model, scene_radius, noise, grad_threshold=0.0002, split_factor=2):
-    """GaussianModel.py:234-245 with clone (:179-197) and split (:199-228).
-
-    ``noise``: the standard-normal draws behind ``torch.normal(0, std)`` of the split, shape
-    [2 * num_split, 3] (or more rows; the first 2 * num_split are used): sample = noise * std.
-    Returns (model, num_clone, num_split).
-    """
-    assert split_factor == 2
+def clone(model, mask):
+    """GaussianModel.clone (GaussianModel.py:179-197): the masked rows appended after the live rows, the
+    capacity doubled when the new size reaches it, the statistics zeroed.  Returns (model, num_clone)."""
     m = {k: np.array(v, copy=True) for k, v in model.items()}
     size = int(m["size"])
-    with np.errstate(divide="ignore", invalid="ignore"):
-        grads = (m["coords_grads"] / m["denom"].astype(F32)).astype(F32)   # :236, over the capacity
-    grads[np.isnan(grads)] = 0.0                                           # :237
-    thr = F32(0.01) * F32(scene_radius)
-    smax = m["scale"][:size].max(axis=1)                                   # raw (log) scale, as the reference compares it
-    clone_mask = (np.abs(grads[:size, 0]) >= F32(grad_threshold)) & (smax <= thr)   # :240
-    # ---- clone (:179-197)
-    num_clone = int(clone_mask.sum())
+    mask = np.asarray(mask, bool)
+    num_clone = int(mask.sum())
     if num_clone:
         new_size = size + num_clone
         if new_size >= m["coords"].shape[0]:
             m = _expand(m, 2 * m["coords"].shape[0])
         for k in PARAM_KEYS:
-            m[k][size:new_size] = m[k][:size][clone_mask]
+            m[k][size:new_size] = m[k][:size][mask]
         m["coords_grads"] = np.zeros((m["coords"].shape[0], 1), F32)
         m["denom"] = np.zeros((m["coords"].shape[0], 1), np.int32)
         size = new_size
-    # ---- split mask (:242-244): the averaged statistics of the rows below the OLD capacity
-    pad = np.zeros((size, 1), F32)
-    k = min(size, grads.shape[0])
-    pad[:k] = grads[:size]
-    smax = m["scale"][:size].max(axis=1)
-    split_mask = (np.abs(pad[:, 0]) >= F32(grad_threshold)) & (smax > thr)
-    # ---- split (:199-228)
+    m["size"] = size
+    return m, num_clone
+
+
+def split(model, mask, noise, split_factor=2):
+    """GaussianModel.split (GaussianModel.py:199-228) with split_factor 2.
+
+    ``noise``: the standard-normal draws behind ``torch.normal(0, std)``, shape [2 * num_split, 3] (or more
+    rows; the first 2 * num_split are used): sample = noise * std.  Returns (model, num_split)."""
+    assert split_factor == 2
+    m = {k: np.array(v, copy=True) for k, v in model.items()}
+    size = int(m["size"])
+    split_mask = np.asarray(mask, bool)
     num_split = int(split_mask.sum())
     if num_split:
         new_size = size + num_split
@@ -154,6 +149,30 @@ def densify(model, scene_radius, noise, grad_threshold=0.0002, split_factor=2):
         m["denom"] = np.zeros((m["coords"].shape[0], 1), np.int32)
         size = new_size
     m["size"] = size
+    return m, num_split
+
+
+def densify(model, scene_radius, noise, grad_threshold=0.0002, split_factor=2):
+    """GaussianModel.py:234-245: the two selections around ``clone`` and ``split`` above.
+    Returns (model, num_clone, num_split)."""
+    assert split_factor == 2
+    m = {k: np.array(v, copy=True) for k, v in model.items()}
+    size = int(m["size"])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        grads = (m["coords_grads"] / m["denom"].astype(F32)).astype(F32)   # :236, over the capacity
+    grads[np.isnan(grads)] = 0.0                                           # :237
+    thr = F32(0.01) * F32(scene_radius)
+    smax = m["scale"][:size].max(axis=1)                                   # raw (log) scale, as the reference compares it
+    clone_mask = (np.abs(grads[:size, 0]) >= F32(grad_threshold)) & (smax <= thr)   # :240
+    m, num_clone = clone(m, clone_mask)
+    size = int(m["size"])
+    # split mask (:242-244): the averaged statistics of the rows below the OLD capacity
+    pad = np.zeros((size, 1), F32)
+    k = min(size, grads.shape[0])
+    pad[:k] = grads[:size]
+    smax = m["scale"][:size].max(axis=1)
+    split_mask = (np.abs(pad[:, 0]) >= F32(grad_threshold)) & (smax > thr)
+    m, num_split = split(m, split_mask, noise, split_factor)
     return m, num_clone, num_split
 
 

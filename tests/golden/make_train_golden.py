@@ -1,4 +1,4 @@
-"""Generates tests/golden/adam_*.npz, stats_*.npz, densify_*.npz and remove_*.npz by running the
+"""Generates tests/golden/adam_*.npz, stats_*.npz, densify_*.npz, clone_*.npz, split_*.npz and remove_*.npz by running the
 REFERENCE's training-state code on the CPU:
 
 * ``torch.optim.Adam(params, lr=1e-3, betas=(0.5, 0.999))`` exactly as ``Trainer.py:24`` builds it,
@@ -171,6 +171,42 @@ def make_densify(GM):
         save(name, **out)
 
 
+def make_clone_split(GM):
+    """GaussianModel.clone(mask) and GaussianModel.split(mask) (GaussianModel.py:179-228) called on their own
+    with arbitrary masks, as a caller other than densify would."""
+    # name: method, capacity, size, fraction of rows in the mask
+    cases = {
+        "clone_room": ("clone", 64, 40, 0.3),
+        "clone_grow": ("clone", 44, 40, 0.5),         # the new size reaches the capacity: doubled
+        "clone_none": ("clone", 64, 40, 0.0),         # empty mask: nothing changes, the statistics persist
+        "split_room": ("split", 300, 130, 0.4),
+        "split_grow": ("split", 40, 33, 0.6),
+        "split_none": ("split", 64, 40, 0.0),
+    }
+    for seed, (name, (method, cap, size, frac)) in enumerate(cases.items()):
+        gen = torch.Generator().manual_seed(980 + seed)
+        m = new_model(GM, cap, size, gen, scale_mean=-0.5)
+        set_stats(m, gen, 0.5)
+        mask = torch.rand(size, generator=gen) < frac
+        out = snapshot(m, "in_")
+        out["mask"] = mask.numpy().copy()
+        n = int(mask.sum())
+        torch.manual_seed(5000 + seed)
+        noise = torch.randn(max(2 * n, 1), 3)        # what torch.normal draws below, standardised
+        torch.manual_seed(5000 + seed)
+        pre_scale = m._scale.detach().clone()
+        with torch.no_grad():
+            getattr(m, method)(mask)
+        out.update(snapshot(m, "out_"))
+        if method == "split" and n:
+            rows = np.nonzero(mask.numpy())[0]
+            want = torch.log(torch.exp(pre_scale[rows]) / 1.6).numpy()
+            np.testing.assert_allclose(out["out_scale"][rows], want, rtol=1e-6)
+        out["noise"] = noise.numpy().copy()
+        print(f"  {name}: size {size} -> {int(m._size)}, capacity {cap} -> {m.capacity}")
+        save(name, **out)
+
+
 def make_remove(GM):
     for seed, (name, cap, size, frac) in enumerate((("remove_few", 40, 33, 0.1), ("remove_many", 300, 280, 0.45),
                                                      ("remove_none", 20, 16, 0.0))):
@@ -219,6 +255,7 @@ def main():
     make_adam()
     make_stats(GM)
     make_densify(GM)
+    make_clone_split(GM)
     make_remove(GM)
 
 

@@ -162,6 +162,48 @@ def test_densify_matches_reference(name):
     assert ([id(p) for p in m.parameters()] != ids_before) == grew     # new nn.Parameters only when the capacity grew
 
 
+@pytest.mark.parametrize("name", fixtures("clone") + fixtures("split"))
+def test_clone_and_split_match_reference(name):
+    """GaussianModel.clone(mask) / GaussianModel.split(mask) (GaussianModel.py:179-228) called on their own."""
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = model_from(d, "in_")
+    mask = torch.from_numpy(d["mask"]).to(dev())
+    if name.startswith("clone"):
+        n = m.clone(mask)
+    else:
+        n = m.split(mask, noise=torch.from_numpy(d["noise"]).to(dev()))
+    assert n == int(d["mask"].sum())
+    assert_model(model_dict(m), lambda k: d["out_" + k], name)
+
+
+def test_clone_then_split_is_what_densify_does():
+    """densify = selection + clone + selection + split: the two methods called one after the other with the
+    masks densify derives give the rows densify gives."""
+    d = np.load(os.path.join(GOLDEN, "densify_room.npz"))
+    a, b = model_from(d, "in_"), model_from(d, "in_")
+    noise = torch.from_numpy(d["noise"]).to(dev())
+    n_clone, n_split = a.densify(torch.tensor(float(d["scene_radius"])), noise=noise)
+    assert n_clone and n_split
+    size = b._size
+    grads = (b._coords_grads / b._denom)[:size, 0]
+    grads[grads.isnan()] = 0.0
+    thr = 0.01 * float(d["scene_radius"])
+    smax = b._scale[:size].max(dim=1).values
+    hot = grads.abs() >= 0.0002
+    assert b.clone(hot & (smax <= thr)) == n_clone
+    # the split mask covers the rows appended by clone too (GaussianModel.py:242-245): their averaged
+    # statistics are those of the rows at and above the old size
+    pad = torch.zeros(b._size, device=dev())
+    full = (torch.from_numpy(d["in_coords_grads"]).to(dev()) / torch.from_numpy(d["in_denom"]).to(dev()))[:, 0]
+    full[full.isnan()] = 0.0
+    k = min(b._size, full.shape[0])
+    pad[:k] = full[:k]
+    smax = b._scale[:b._size].max(dim=1).values
+    assert b.split((pad.abs() >= 0.0002) & (smax > thr), noise=noise) == n_split
+    want = model_dict(a)
+    assert_model(model_dict(b), lambda key: want[key], "clone + split")
+
+
 @pytest.mark.parametrize("name", fixtures("remove"))
 def test_remove_matches_reference(name):
     d = np.load(os.path.join(GOLDEN, name + ".npz"))

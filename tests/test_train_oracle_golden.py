@@ -39,6 +39,7 @@ def assert_model(got, d, prefix, exact_rows=False):
 
 def test_fixture_coverage():
     assert len(fixtures("adam")) >= 2 and len(fixtures("densify")) >= 6 and len(fixtures("remove")) >= 3 and fixtures("stats")
+    assert len(fixtures("clone")) >= 3 and len(fixtures("split")) >= 3
     grow = [np.load(os.path.join(GOLDEN, n + ".npz")) for n in fixtures("densify")]
     assert any(d["out_coords"].shape[0] == 4 * d["in_coords"].shape[0] for d in grow)      # capacity doubled twice
     assert any(int(d["num_clone"]) and int(d["num_split"]) for d in grow)
@@ -77,6 +78,18 @@ def test_densify_oracle_matches_reference(name):
     d = np.load(os.path.join(GOLDEN, name + ".npz"))
     m, n_clone, n_split = to.densify(load_model(d, "in_"), float(d["scene_radius"]), d["noise"])
     assert (n_clone, n_split) == (int(d["num_clone"]), int(d["num_split"]))
+    assert_model(m, d, "out_")
+
+
+@pytest.mark.parametrize("name", fixtures("clone") + fixtures("split"))
+def test_clone_and_split_oracle_match_reference(name):
+    """GaussianModel.clone / GaussianModel.split called on their own with an arbitrary mask."""
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if name.startswith("clone"):
+        m, n = to.clone(load_model(d, "in_"), d["mask"])
+    else:
+        m, n = to.split(load_model(d, "in_"), d["mask"], d["noise"])
+    assert n == int(d["mask"].sum())
     assert_model(m, d, "out_")
 
 

@@ -19,7 +19,7 @@ def _names():
 
 def golden_names():
     """Fixtures of the render path (tests/golden/make_golden.py)."""
-    other = ("loss_", "adam_", "stats_", "densify_", "remove_", "camera_")   # fixtures of the loss and of the training-state updates
+    other = ("loss_", "adam_", "stats_", "densify_", "clone_", "split_", "remove_", "camera_")   # fixtures of the loss and of the training-state updates
     return [n for n in _names() if not n.startswith(other) and not n.startswith(("nonfinite_", "nancolour_"))]
 
 
