@@ -67,6 +67,11 @@ class GaussianModel(GaussianParams):
         self._device = coords.device
         self._coords_grads = torch.zeros((cap, 1), dtype=torch.float32, device=coords.device)
         self._denom = torch.zeros((cap, 1), dtype=torch.int32, device=coords.device)
+        # the activation attributes of GaussianModel.py:29-32, under the reference's names (its spelling)
+        self.opactiy_activation = torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+        self.scale_activation = torch.exp
+        self.scale_inv_activation = torch.log
 
     @staticmethod
     def from_pcd(pcd, device="cuda", max_sh_degree: int = 3) -> "GaussianModel":

@@ -34,6 +34,8 @@ def test_reference_constructor_forms():
     assert m._sh.shape == (0, 3, 16) and len(list(m.parameters())) == 5
     assert GaussianModel(2)._sh.shape == (0, 3, 9) and GaussianModel(max_sh_degree=1).max_sh_degree == 1
     assert len(m.construct_list_of_attributes()) == 62
+    import torch
+    assert m.scale_activation is torch.exp and m.scale_inv_activation is torch.log and m.opactiy_activation is torch.sigmoid   # GaussianModel.py:29-32
 
 
 def test_covariance_and_properties_match_the_reference():
