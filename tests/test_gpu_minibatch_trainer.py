@@ -1,7 +1,6 @@
 """GPU: the data-parallel training step (trainer.MinibatchTrainer) and the densification statistics
 of views that are spread over ranks (densify.stats_delta + minibatch.reduce_densify_stats), in one
-process.  The run with two real ranks is tools/two_rank_trainer.py (it needs a launcher that has not
-touched the GPU)."""
+process.  The run with two real ranks is tests/test_zy_two_rank_trainer.py (child processes)."""
 import os
 import sys
 

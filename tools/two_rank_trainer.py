@@ -6,8 +6,8 @@ gradient exchange, densification statistics, densification at iteration 50, remo
         tools/two_rank_trainer.py --out gpurun_out/mbt_rank
     python tools/two_rank_trainer.py --compare gpurun_out/mbt_single.npz gpurun_out/mbt_rank0.npz gpurun_out/mbt_rank1.npz
 
-(RCCL refuses two ranks on one device, hence gloo; the collectives' semantics are the same.  The
-launcher must not have touched the GPU, which is why this is not a pytest case.)
+(RCCL refuses two ranks on one device, hence gloo; the collectives' semantics are the same.
+tests/test_zy_two_rank_trainer.py runs these three commands as child processes.)
 """
 import argparse
 import os
@@ -43,7 +43,7 @@ def run(out, steps, views):
     import faulthandler
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    faulthandler.dump_traceback_later(90, exit=True)      # a collective that never returns names itself
+    faulthandler.dump_traceback_later(240, exit=True)      # a collective that never returns names itself
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     if world > 1:
