@@ -22,33 +22,34 @@ import torch
 
 
 class _Pose:
-    """Position + unit quaternion (w, x, y, z) + scale, like ``Utils/Transform.py:6-25``."""
+    """Position + unit quaternion (w, x, y, z) + per-axis scale, the data of ``Utils/Transform.py:6-25``."""
 
     def __init__(self, position, rotation=None, scale=None):
         self.position = np.asarray(position)
         self.rotation = np.array([1, 0, 0, 0]) if rotation is None else np.asarray(rotation)
         self.scale = np.array([1, 1, 1]) if scale is None else np.asarray(scale)
-        if self.rotation.shape[0] != 4:
-            raise ValueError(f"Rotation should have shape 4 but get {self.rotation.shape[0]}")
-        if self.scale.shape[0] != 3:
-            raise ValueError(f"Scale should have shape 3 but get {self.scale.shape[0]}")
+        if self.rotation.shape != (4,):
+            raise ValueError(f"a pose takes a quaternion of 4 numbers (w, x, y, z), got shape {self.rotation.shape}")
+        if self.scale.shape != (3,):
+            raise ValueError(f"a pose takes 3 scale factors, got shape {self.scale.shape}")
 
     def model2world(self) -> np.ndarray:
+        """translation @ rotation @ scale as three float32 4x4 products (``Utils/Transform.py:28-38,73-84,
+        109-138``).  The entries are evaluated in the inputs' precision with the reference's association -
+        ``2 (w w + x x) - 1`` on the diagonal, ``2 (x y -+ w z)`` off it - and only then stored as float32,
+        which is what makes the inverse below agree with the reference's to the last bit."""
         w, x, y, z = (self.rotation[i] for i in range(4))
-        rot = np.array(
-            [
-                [2 * (w * w + x * x) - 1, 2 * (x * y - w * z), 2 * (x * z + w * y), 0],
-                [2 * (x * y + w * z), 2 * (w * w + y * y) - 1, 2 * (y * z - w * x), 0],
-                [2 * (x * z - w * y), 2 * (y * z + w * x), 2 * (w * w + z * z) - 1, 0],
-                [0, 0, 0, 1],
-            ],
-            dtype=np.float32,
-        )
-        px, py, pz = (self.position[i] for i in range(3))
-        trans = np.array([[1, 0, 0, px], [0, 1, 0, py], [0, 0, 1, pz], [0, 0, 0, 1]], dtype=np.float32)
-        sx, sy, sz = (self.scale[i] for i in range(3))
-        scl = np.array([[sx, 0, 0, 0], [0, sy, 0, 0], [0, 0, sz, 0], [0, 0, 0, 1]], dtype=np.float32)
-        return trans @ rot @ scl
+        rot = np.zeros((4, 4), dtype=np.float32)
+        rot[3, 3] = 1
+        for a, (p, q, r) in enumerate(((x, y, z), (y, z, x), (z, x, y))):     # axis a, then the two after it, cyclically
+            b, c = (a + 1) % 3, (a + 2) % 3
+            rot[a, a] = 2 * (w * w + p * p) - 1
+            rot[a, b] = 2 * (p * q - w * r)      # one axis on
+            rot[a, c] = 2 * (p * r + w * q)      # two axes on
+        place = np.eye(4, dtype=np.float32)
+        place[:3, 3] = [self.position[i] for i in range(3)]
+        stretch = np.diag(np.array([self.scale[0], self.scale[1], self.scale[2], 1], dtype=np.float32))
+        return place @ rot @ stretch
 
     def world2model(self) -> np.ndarray:
         return np.linalg.inv(self.model2world())
@@ -91,21 +92,20 @@ class Camera:
                       sfm_camera.principal_point_x, sfm_camera.principal_point_y, width, height, device=device)
 
     def get_projection_matrix(self, near: float = 0.1, far: float = 100) -> np.ndarray:
-        fov_x = 2 * math.atan(self.width / (2 * self.fx))
-        fov_y = 2 * math.atan(self.height / (2 * self.fy))
-        top = near * math.tan(fov_y / 2)
-        bottom = -top
-        right = near * math.tan(fov_x / 2)
-        left = -right
-        return np.array(
-            [
-                [2 * near / (right - left), 0, 0, -near * (right + left) / (right - left)],
-                [0, 2 * near / (top - bottom), 0, -near * (top + bottom) / (top - bottom)],
-                [0, 0, -(far + near) / (far - near), 2 * far * near / (near - far)],
-                [0, 0, -1, 0],
-            ],
-            dtype=float,
-        )
+        """The symmetric OpenGL frustum of the intrinsics in fp64 (``Utils/Camera.py:48-72``), bit for bit:
+        the reference goes through the field of view, ``near * tan(fov / 2)`` with ``fov = 2 atan(size / 2f)``;
+        doubling and halving are exact, and so is ``right - left = 2 right`` of the symmetric frustum, hence
+        ``2 near / (right - left) = near / right`` to the last bit.  The two off-centre terms are ``-0.0``."""
+        half_w = near * math.tan(math.atan(self.width / (2 * self.fx)))
+        half_h = near * math.tan(math.atan(self.height / (2 * self.fy)))
+        m = np.zeros((4, 4), dtype=float)
+        m[0, 0] = near / half_w
+        m[1, 1] = near / half_h
+        m[0, 3] = m[1, 3] = -0.0
+        m[2, 2] = -(far + near) / (far - near)
+        m[2, 3] = 2 * far * near / (near - far)
+        m[3, 2] = -1.0
+        return m
 
     def get_covariance2d(self, pos, cov3d: torch.Tensor) -> torch.Tensor:
         """``Camera.get_covariance2d`` (``Utils/Camera.py:74-87``): ``J W cov3d W^T J^T`` with the Jacobian
