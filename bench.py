@@ -156,6 +156,10 @@ def main():
             return loss_and_grad(st.img, targets[i], 0.2, 1.0 / args.views)[1]
         return cots[i]
 
+    # (start, end) events on the current stream around the gradient exchange of the breakdown steps: the
+    # stream waits there for the collectives, so the pair spans them and the sh rebuild
+    exchange_events = None
+
     def step(overlap=True):
         # The rank's views are software-pipelined over two streams (minibatch.render_views): stage 1,
         # sorts and lists of the next views run beside the compositing of the current one; ONE pass then
@@ -168,9 +172,15 @@ def main():
         if args.forward_only:
             return
         if g_colors is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if exchange_events is not None else None
+            if ev:
+                ev[0].record()
             reduce_gradients(bucket, g_colors, args.views,
                              lambda g_all: sh_grad_views(all_views, params[0], params[4], list(g_all), bucket.sh),
                              force_collectives=True)
+            if ev:
+                ev[1].record()
+                exchange_events.append(ev)
         if opt is not None:
             live = [st for st in states if st.num_visible]
             if use_dist:
@@ -208,10 +218,14 @@ def main():
     # Per-stage breakdown: two more steps with every entry point timed, outside the timed region and on
     # ONE stream, so that every duration is that of the stage running alone.
     with StageTimer() as timer:
+        exchange_events = [] if use_dist else None
         for _ in range(2):
             step(overlap=False)
         sync()
+        exchange = exchange_events
+        exchange_events = None
     stage = timer.summary()
+    exchange_ms = sum(a.elapsed_time(b) for a, b in exchange) / len(exchange) if exchange else None
     breakdown_steps = 2
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -278,6 +292,7 @@ def main():
                         "stream and share the CUs with it (avg_launch_ms_alone: the same launch with nothing beside it)",
             },
             "stage_ms_per_view": {k: round(v, 4) for k, v in stage_ms.items()},
+            "exchange_ms_per_step": None if exchange_ms is None else round(exchange_ms, 4),
             "stage_hbm_frac": {k: round(ab[a] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                for k, a in (("preprocess_fwd", "preprocess_fwd"), ("composite_fwd", "composite_fwd"),
                                             ("composite_bwd", "composite_bwd"), ("preprocess_bwd", "preprocess_bwd"))
