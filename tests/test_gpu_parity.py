@@ -161,6 +161,21 @@ def test_mid_size_vs_oracle(oracle_mod, kind, n, w, h, deg, tile):
     compare(hip, ora)
 
 
+@pytest.mark.parametrize("tile", [64, 16])
+def test_config1_like_50k_deg0_180x180_vs_oracle(oracle_mod, tile):
+    """The shape of the head-scene configuration: about 50 k Gaussians, SH degree 0, a 720-pixel view
+    downscaled by four, a camera on an orbit; at the reference's default tile edge and at 16."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.scenes import orbit_scene
+    sc = orbit_scene(50_000, 180, 180, 0, 3, 8, 5)
+    a = _scene_arrays(sc)
+    cot = torch.rand(180, 180, 3, generator=torch.Generator().manual_seed(7)).numpy()
+    hip = run_hip(cot=cot, tile=tile, **a)
+    ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 0, 180, 180, tile, a["w2m"],
+                            a["proj"], a["cam_pos"], dimg=cot)
+    compare(hip, ora)
+
+
 def test_config2_200k_800x800_vs_oracle(oracle_mod):
     """The single-view parity configuration: 200k Gaussians, SH degree 3, one 800x800 view, forward + backward."""
     import gsplat_amd  # noqa: F401
