@@ -202,14 +202,16 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         half_full(0, R, red, o, bdx, adx2);
         half_full(1, R, red, o, bdx, adx2);
     };
-    // odd lanes touch the record before the one named (offset - 64, in wrapping 32-bit arithmetic)
-    const uint32_t touch_off = (threadIdx.x & 1) ? 0u - 64u : 0u;
+    // odd lanes touch the record before the one named (offset - 64, in wrapping 32-bit arithmetic); the
+    // named record is never the stream's first one unless the stream has no other (touch_floor)
+    const uint32_t touch_off = ((threadIdx.x & 1) && w.total > 1u) ? 0u - 64u : 0u;
     float sink = 0.0f;
     if (w.begin < w.end) {
         // Two record buffers, alternating: while one is blended the other is in flight.  All stream
         // positions are 32-bit byte offsets (64 bytes per record).
         const uint32_t off_last = (w.end - 1) * 64u;
         const uint32_t off_stream_last = (w.total - 1) * 64u;   // the touches may run into the next lists
+        const uint32_t touch_floor = min(64u, off_stream_last);
         uint32_t off = w.begin * 64u;
         Rec A, B;
         rec_request(stream_rec, off, A);
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
             rec_wait(A);
             uint32_t next = min(off + 64u, off_last);
             rec_request(stream_rec, next, B);
-            l2_touch(stream_rec, min(off + kTouchAhead * 64u, off_stream_last), touch_off, sink);
+            l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor), touch_off, sink);
             blend(A);
             if (off == off_last) break;
             off = next;
@@ -470,7 +472,8 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     const uint32_t off_first = w.begin * 64u;
     uint32_t off = (w.end - 1) * 64u;   // the caller guarantees a non-empty list
     uint32_t k = w.end - 1;
-    const uint32_t touch_off = (threadIdx.x & 1) * 64u;
+    // (odd lanes touch the record after the one named; a stream of a single record has none)
+    const uint32_t touch_off = ((threadIdx.x & 1) && w.total > 1u) ? 64u : 0u;
     float sink = 0.0f;
     Rec A, B;
     rec_request(stream_rec, off, A);
@@ -565,7 +568,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // front to back with two record buffers and the L2 touch-ahead, as in composite_fwd_kernel: a
             // loop that waits for every record before it asks for the next one runs at the latency of L2
             const uint32_t off_last = (w.end - 1) * 64u, off_stream_last = (w.total - 1) * 64u;
-            const uint32_t touch_off = (threadIdx.x & 1) ? 0u - 64u : 0u;
+            const uint32_t touch_floor = min(64u, off_stream_last);
+            const uint32_t touch_off = ((threadIdx.x & 1) && w.total > 1u) ? 0u - 64u : 0u;
             uint32_t off = w.begin * 64u, idx = 0u;
             float sink = 0.0f;
             Rec A, B;
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 rec_wait(A);
                 uint32_t next = min(off + 64u, off_last);
                 rec_request(stream_rec, next, B);
-                l2_touch(stream_rec, min(off + kTouchAhead * 64u, off_stream_last), touch_off, sink);
+                l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor), touch_off, sink);
                 forward_step(A, idx);
                 if (off == off_last) break;
                 off = next;

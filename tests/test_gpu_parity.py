@@ -203,6 +203,23 @@ def test_screen_coords_offset_moves_the_splat(oracle_mod):
     compare(hip, ora)
 
 
+@pytest.mark.parametrize("tile", [16, 64])
+def test_single_pair_view(oracle_mod, tile):
+    """One visible Gaussian in an image smaller than one tile: the record stream of the view holds exactly one
+    (tile, Gaussian) pair, so nothing lies before or behind the record the compositing waves fetch."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.scenes import synthetic_scene
+    sc = synthetic_scene(1, 12, 10, 1, 3)
+    a = _scene_arrays(sc)
+    a["coords"] = np.array([[0.1, -0.05, -3.0]], np.float32)
+    cot = torch.rand(12, 10, 3, generator=torch.Generator().manual_seed(7)).numpy()
+    hip = run_hip(cot=cot, tile=tile, **a)
+    assert hip["num_pairs"] == 1
+    ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 1, 12, 10, tile, a["w2m"],
+                            a["proj"], a["cam_pos"], dimg=cot)
+    compare(hip, ora)
+
+
 def test_backward_is_reproducible():
     """No float atomics at tile 16: two runs give bit-identical images and gradients."""
     import gsplat_amd  # noqa: F401

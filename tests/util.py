@@ -76,7 +76,15 @@ def assert_close(got, ref, name="", rtol=RTOL, atol_frac=ATOL_FRAC, outlier_frac
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
-    assert np.isfinite(got).all() == np.isfinite(ref).all(), f"{name}: non-finite mismatch"
+    # non-finite values must sit at the same positions (NaN for NaN, infinities with their sign); the
+    # tolerance applies to the finite remainder
+    gn, rn = np.isnan(got), np.isnan(ref)
+    assert np.array_equal(gn, rn), f"{name}: NaN at {np.argwhere(gn != rn)[:5].tolist()} on one side only"
+    gi, ri = np.isinf(got), np.isinf(ref)
+    assert np.array_equal(gi, ri) and np.array_equal(got[gi], ref[ri]), f"{name}: infinities differ"
+    finite = ~(gn | gi)
+    if not finite.all():
+        got, ref = np.where(finite, got, 0.0), np.where(finite, ref, 0.0)
     scale = float(np.abs(ref).max()) if ref.size else 0.0
     tol = rtol * np.abs(ref) + atol_frac * scale
     err = np.abs(got - ref)
