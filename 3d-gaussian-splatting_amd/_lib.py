@@ -23,6 +23,7 @@ SYMBOLS = (
     "gsr_last_error", "gsr_version", "gsr_preprocess_fwd", "gsr_preprocess_bwd", "gsr_preprocess_bwd_workspace_bytes",
     "gsr_pair_reduce", "gsr_preprocess_bwd_views", "gsr_sh_grad_views",
     "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_sort_pairs64", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
+    "gsr_exclusive_scan_static",
     "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order",
     "gsr_composite_fwd", "gsr_composite_bwd",
     "gsr_loss_workspace_bytes", "gsr_loss_fwd_bwd",
@@ -93,6 +94,7 @@ def load():
     lib.gsr_sort_pairs.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
     lib.gsr_sort_pairs64.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, vp]
     lib.gsr_exclusive_scan.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_size_t, vp]
+    lib.gsr_exclusive_scan_static.argtypes = [vp, vp, C.c_uint32, vp, vp]
     lib.gsr_bin_offsets.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_bin_lists.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_tile_order.argtypes = [C.POINTER(GsrView), vp, vp, vp]

@@ -1,6 +1,8 @@
 // Device-wide exclusive scan and stable least-significant-digit radix sort of (u32 key, u32 value)
 // pairs.  Both are bandwidth-bound passes over HBM; wave64 primitives (ballot, shuffles) do the
 // in-block work.  Nothing here allocates: scratch comes from the caller's workspace.
+#include <mutex>
+
 #include "gsr_common.hpp"
 
 namespace {
@@ -349,6 +351,57 @@ extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n,
                                   size_t workspace_bytes, void *stream)
 {
     return gsr_exclusive_scan_along(in, nullptr, out, n, total, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+// ---- exclusive scan without a workspace argument ---------------------------------------------
+// For callers that cannot allocate (code under HIP graph capture, tight serving loops): the block sums,
+// which gsr_exclusive_scan keeps in the caller's workspace, live in a file-scope device array.  Every GPU
+// the library runs on holds its own copy of the array at its own address for the life of the process;
+// the address is looked up once per device, with that device current, and kept.
+constexpr uint32_t kStaticScanMaxN = 1u << 24;                        // 16 777 216 elements
+constexpr uint32_t kStaticScanSums = kStaticScanMaxN / SCAN_TILE;     // 8192 block sums = 32 KiB
+static __device__ __align__(256) uint32_t scratch[kStaticScanSums];
+
+constexpr int kMaxDevices = 64;
+static uint32_t *g_scan_scratch[kMaxDevices];      // device address of `scratch` per device, null until looked up
+static std::mutex g_scan_scratch_lock;
+
+// The device address of this device's copy of `scratch` (never the array's name: in host code that is a
+// host-side stand-in, not a device address).
+static int static_scan_scratch(uint32_t **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        gsr_set_error("gsr_exclusive_scan_static: no current device (%s)", e != hipSuccess ? hipGetErrorString(e) : "index out of range");
+        return GSR_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> hold(g_scan_scratch_lock);
+    if (!g_scan_scratch[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            gsr_set_error("gsr_exclusive_scan_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return GSR_ERR_LAUNCH;
+        }
+        g_scan_scratch[dev] = (uint32_t *)ptr;
+    }
+    *out = g_scan_scratch[dev];
+    return GSR_OK;
+}
+
+extern "C" int gsr_exclusive_scan_static(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *stream)
+{
+    if (n > kStaticScanMaxN) {
+        gsr_set_error("gsr_exclusive_scan_static: %u elements exceed the built-in scratch (at most %u); use "
+                      "gsr_exclusive_scan with a workspace", n, kStaticScanMaxN);
+        return GSR_ERR_ARG;
+    }
+    uint32_t *sums = nullptr;
+    if (int e = static_scan_scratch(&sums)) return e;
+    // the kernels overwrite the block sums they read (one per 2048 elements), nothing has to start at zero
+    return gsr_exclusive_scan_along(in, nullptr, out, n, total, sums, kStaticScanSums * sizeof(uint32_t), stream, nullptr,
+                                    nullptr);
 }
 
 extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)

@@ -167,6 +167,17 @@ size_t gsr_scan_workspace_bytes(uint32_t n);
 int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* gsr_exclusive_scan for callers that cannot allocate device memory or hand over a workspace (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same results as gsr_exclusive_scan, bit for bit; the block sums live in a 32 KiB array
+ * inside the library's code object (one copy per GPU, held until the process ends), so
+ * n <= GSR_SCAN_STATIC_MAX_N - larger inputs are refused with GSR_ERR_ARG.  The call allocates and frees
+ * nothing; the first call on a device looks up the array's device address (no allocation either).
+ * All calls on one GPU share that array: calls that overlap on one GPU (two streams, two host threads)
+ * race - order them, or use gsr_exclusive_scan with separate workspaces. */
+#define GSR_SCAN_STATIC_MAX_N (1u << 24)
+int gsr_exclusive_scan_static(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *stream);
+
 /* Depth order of the Gaussians and the slot ranges of their pairs.
  * order[N]: Gaussian indices by (depth_key, index) ascending - visible ones first;
  * slot_base[N] (N-indexed): first emission slot of each Gaussian; slots follow depth order, so
