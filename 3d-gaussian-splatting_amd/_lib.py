@@ -25,7 +25,7 @@ SYMBOLS = (
     "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_sort_pairs64", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
     "gsr_exclusive_scan_static",
     "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order",
-    "gsr_composite_fwd", "gsr_composite_bwd",
+    "gsr_composite_fwd", "gsr_composite_bwd", "gsr_pairgrad_parts",
     "gsr_loss_workspace_bytes", "gsr_loss_fwd_bwd",
     "gsr_adam_step", "gsr_knn_dist2",
     "gsr_densify_stats", "gsr_densify_select_workspace_bytes", "gsr_densify_select", "gsr_densify_apply",
@@ -87,7 +87,9 @@ def load():
     vp = C.c_void_p
     lib.gsr_preprocess_fwd.argtypes = [C.POINTER(GsrView)] + [vp] * 16
     lib.gsr_preprocess_bwd.argtypes = [C.POINTER(GsrView)] + [vp] * 15 + [C.c_int, vp, C.c_size_t, vp]
-    lib.gsr_pair_reduce.argtypes = [C.c_uint32, vp, vp, vp, vp, vp, vp]
+    lib.gsr_pair_reduce.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    lib.gsr_pairgrad_parts.restype = C.c_uint32
+    lib.gsr_pairgrad_parts.argtypes = [C.c_int]
     lib.gsr_preprocess_bwd_views.argtypes = ([C.POINTER(GsrView), C.c_uint32] + [vp] * 5 + [C.POINTER(vp)] * 2 + [vp] * 5 +
                                              [C.POINTER(vp), C.POINTER(vp), C.c_int, vp])
     lib.gsr_sh_grad_views.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, C.POINTER(vp), vp, C.c_int, vp]

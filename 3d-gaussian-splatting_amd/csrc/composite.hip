@@ -54,7 +54,7 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
 {
     const int S = (v.L + 15) >> 4;
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned wv = blockIdx.x * WAVES_PER_BLOCK + wave_in_block;
+    const unsigned wv = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const unsigned per_tile = (unsigned)(S * S);
     const unsigned turn = wv / per_tile;
     if (turn >= (unsigned)v.T) return false;
@@ -308,16 +308,45 @@ __device__ inline RecordLanes record_lanes(int lane)
     return L;
 }
 
+// How the gradient record of a (tile, Gaussian) pair reaches pairgrad.
+//   kOneBlock:  the tile is one 16x16 block, its wave stores the record (plain stores);
+//   kTileGroup: the tile has 4, 9 or 16 blocks; they are composited by workgroups of 4 (3 for 9 blocks) waves,
+//               one wave per block.  Every wave leaves its part of a record in LDS, the workgroup adds the parts
+//               in block order, a chunk of entries at a time, and stores the sum in the workgroup's own row of
+//               pairgrad: a pair owns gsr_pairgrad_parts() consecutive rows, one per workgroup of its tile, and
+//               the per-Gaussian sums add them in row order.  No atomics: the result does not depend on timing.
+//               (Small workgroups, several per compute unit: while one waits at its barrier the others run.)
+//   kAtomic:    more than 16 blocks per tile: independent waves add into a zeroed pairgrad with float atomics.
+enum StoreMode { kOneBlock = 0, kAtomic = 1, kTileGroup = 2 };
+constexpr uint32_t kGroupChunk = 32;   // entries between two reductions of a tile group (two chunk buffers; 16 to 64 time alike)
+constexpr uint32_t kGroupMaxWaves = 4;
+
+__host__ __device__ inline int group_waves(int S) { return S == 3 ? 3 : 4; }   // blocks per workgroup, S = blocks per tile edge
+
+// Where a wave of a tile group leaves its parts (unused by the other modes).
+struct GroupSlot {
+    float *parts;        // LDS [2][kGroupChunk][kGroupMaxWaves][GSR_PAIRGRAD_FLOATS]: the chunk being filled and the one before
+    uint32_t *slots;     // LDS [2][kGroupChunk]: emission slot of each entry
+    uint32_t block, blocks, entry;   // this wave's block inside the group, blocks of the group, entry of the chunk being filled
+    uint32_t buf;        // chunk buffer being filled (0 / 1)
+    uint32_t part, nparts;           // the group's row among the rows of a pair, rows per pair
+};
+
 // dst = pairgrad + byte offset `rec_off` of the record; the writers are the lanes of `writers`.
-template <bool ATOMIC>
+template <int MODE>
 __device__ inline void put_record(float *pairgrad, uint32_t rec_off, uint32_t lane_off, float val,
-                                  unsigned long long writers)
+                                  unsigned long long writers, const GroupSlot &gs)
 {
     const uint32_t voff = lane_off + rec_off;
-    if (ATOMIC) {
+    if (MODE == kAtomic) {
         // several waves share the record; it was zeroed by the launcher
         if (((writers >> (threadIdx.x & 63)) & 1ull) && val != 0.0f)
             atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(pairgrad) + voff), val);
+    } else if (MODE == kTileGroup) {
+        const uint32_t e = gs.buf * kGroupChunk + gs.entry;
+        if ((writers >> (threadIdx.x & 63)) & 1ull)
+            gs.parts[(e * kGroupMaxWaves + gs.block) * GSR_PAIRGRAD_FLOATS + (lane_off >> 2)] = val;
+        if (gs.block == 0 && (threadIdx.x & 63) == 0) gs.slots[e] = rec_off / (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));
     } else {
         // every lane of the wave is active here: set the writers, store, restore
         asm volatile("s_mov_b64 exec, %3\n\t"
@@ -329,10 +358,28 @@ __device__ inline void put_record(float *pairgrad, uint32_t rec_off, uint32_t la
     }
 }
 
+// Adds up the parts of the `count` entries a tile group has filled in and stores the sums (all threads of
+// the workgroup), then turns to the other chunk buffer.  One barrier per chunk: a wave writes into this buffer
+// again only after the NEXT chunk's barrier, which every wave passes after its share of these reads.
+__device__ inline void group_flush(GroupSlot &gs, uint32_t count, float *pairgrad)
+{
+    __syncthreads();
+    const uint32_t first = gs.buf * kGroupChunk;
+    for (uint32_t i = threadIdx.x; i < count * GSR_PAIRGRAD_FLOATS; i += blockDim.x) {
+        const uint32_t e = i / GSR_PAIRGRAD_FLOATS, f = i - e * GSR_PAIRGRAD_FLOATS;
+        const float *part = gs.parts + (first + e) * kGroupMaxWaves * GSR_PAIRGRAD_FLOATS + f;
+        float sum = part[0];
+        for (uint32_t b = 1; b < gs.blocks; ++b) sum += part[b * GSR_PAIRGRAD_FLOATS];   // block order: reproducible
+        pairgrad[((size_t)gs.slots[first + e] * gs.nparts + gs.part) * GSR_PAIRGRAD_FLOATS + f] = sum;
+    }
+    gs.buf ^= 1u;
+    gs.entry = 0;
+}
+
 // Full record, floats: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2, dL/d(opacity),
 // dL/d(red), dL/d(green), then four partial sums of dL/d(blue).
-template <bool ATOMIC>
-__device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, uint32_t rec_off, float unscale, float vx,
+template <int MODE>
+__device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, uint32_t rec_off, const GroupSlot &gs, float unscale, float vx,
                                          float vy, float xx, float xy, float yy, float o, float r, float g, float b)
 {
     // pairing order chosen so that group g of 8 lanes ends up with record float g
@@ -341,25 +388,25 @@ __device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, 
     const float n1 = merge_rows(m2, m3);   // rows: vy, xy, o,  g
     const float all8 = sum8(merge_half_rows(n0, n1));
     const float blue = sum16(b);
-    put_record<ATOMIC>(pairgrad, rec_off, L.full_off, (L.full_main ? all8 : blue) * unscale, kFullWriters);
+    put_record<MODE>(pairgrad, rec_off, L.full_off, (L.full_main ? all8 : blue) * unscale, kFullWriters, gs);
 }
 
 // Colour-only record (the clamp blocks every other gradient of the entry).
-template <bool ATOMIC>
-__device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad, uint32_t rec_off, float unscale, float r,
+template <int MODE>
+__device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad, uint32_t rec_off, const GroupSlot &gs, float unscale, float r,
                                            float g, float b)
 {
     const float rows = sum16(merge_rows(merge_halves(r, g), b));   // rows: red, blue(0-1), green, blue(2-3)
-    put_record<ATOMIC>(pairgrad, rec_off, L.col_off, L.col_zero ? 0.0f : rows * unscale, kColWriters);
+    put_record<MODE>(pairgrad, rec_off, L.col_off, L.col_zero ? 0.0f : rows * unscale, kColWriters, gs);
 }
 
 // Reverse sweep of one list for the 4 pixels of a lane.  CHECK: pixel j only takes part in
 // entries with index (k - begin) < nstop[j].
-template <bool CHECK, bool ATOMIC>
+template <bool CHECK, int MODE>
 __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ stream_rec, const float pxf,
                                  const f2 (&pyf)[2], f2 (&T)[2], const f2 (&gr)[2], const f2 (&gg)[2],
                                  const f2 (&gb)[2], const uint32_t (&nstop)[4], const float unscale,
-                                 float *__restrict__ pairgrad)
+                                 float *__restrict__ pairgrad, GroupSlot gs)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
     const f2 py_top = pyf[0];
@@ -445,14 +492,14 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     };
     auto entry = [&](const Rec &R, uint32_t k) {
         const uint32_t rec_off = R_slot(R) * (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));   // a Gaussian's records are contiguous
-        const uint32_t flags = block_flags<ATOMIC>(R_flags(R), w.flag_shift);   // ATOMIC = several blocks per tile
+        const uint32_t flags = block_flags<MODE != kOneBlock>(R_flags(R), w.flag_shift);
         const f2 z = splat(0.f);
         s_r = s_g = s_b = z;
         const float red = R_r(R);
         if (flags == kLowBoth) {
             half_low(0, R, k, red);
             half_low(1, R, k, red);
-            reduce_store_colour<ATOMIC>(lanes, pairgrad, rec_off, unscale, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+            reduce_store_colour<MODE>(lanes, pairgrad, rec_off, gs, unscale, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
             return;
         }
         s_vx = s_vy = s_xx = s_xy = s_yy = s_o = z;
@@ -464,7 +511,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         if (flags & kLowBottom) half_low(1, R, k, red); else half_full(1, R, k, red, o, dx, adx2, bdx);
         // (an entry that is not flagged but whose clamp blocks every pixel anyway - one in a thousand -
         // simply stores zero sums)
-        reduce_store_full<ATOMIC>(lanes, pairgrad, rec_off, unscale, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
+        reduce_store_full<MODE>(lanes, pairgrad, rec_off, gs, unscale, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
                                   s_yy.x + s_yy.y, s_o.x + s_o.y, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
     };
     // back to front, two record buffers alternating (see composite_fwd_kernel); k is only needed by
@@ -484,6 +531,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         // the two lines below the one sixteen entries down (never below the start of the stream)
         l2_touch(stream_rec, max(off, (kTouchAhead + 1) * 64u) - (kTouchAhead + 1) * 64u, touch_off, sink);
         entry(A, k);
+        if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
         if (off == off_first) break;
         off = next;
         if (CHECK) --k;
@@ -491,6 +539,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         next = max(off, off_first + 64u) - 64u;
         rec_request(stream_rec, next, A);
         entry(B, k);
+        if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
         if (off == off_first) break;
         off = next;
         if (CHECK) --k;
@@ -498,16 +547,17 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     rec_wait(A);
     rec_wait(B);
     l2_touch_drain(sink);
+    // (every wave of a tile group walks the same list: the barriers inside the flushes match up)
+    if (MODE == kTileGroup && gs.entry != 0) group_flush(gs, gs.entry, pairgrad);
 }
 
-// ATOMIC = several waves share a tile (L > 16): their sums meet in pairgrad through float atomics
-// (pairgrad zeroed by the launcher).  Otherwise each record is written once with plain stores.
+// MODE: how the blocks of a tile combine their sums (StoreMode above).
 // A wave none of whose pixels ran below kTinyT takes the plain sweep, the others the checked one.
 // Both live in one launch: the checked waves are few and three times as long, and a launch of their
 // own ran at the latency of a single wave per SIMD.  (Four waves per SIMD: the loop is bound by
 // instruction issue, more resident waves do not help it, and the register budget of four waves
 // holds both sweeps.)
-template <bool ATOMIC>
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                             const uint32_t *__restrict__ tile_order,
                                                             const float *__restrict__ stream_rec,
@@ -517,8 +567,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 {
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
-    if (w.begin >= w.end) return;
+    if (w.begin >= w.end) return;   // (the same for every wave of a tile group)
     raise_wave_priority();
+    GroupSlot gs = {nullptr, nullptr, 0u, 1u, 0u, 0u, 0u, 1u};
+    if (MODE == kTileGroup) {
+        __shared__ float group_parts[2 * kGroupChunk * kGroupMaxWaves * GSR_PAIRGRAD_FLOATS];   // 12 KiB
+        __shared__ uint32_t group_slots[2 * kGroupChunk];
+        const int S = (v.L + 15) >> 4;
+        gs.parts = group_parts;
+        gs.slots = group_slots;
+        gs.blocks = blockDim.x >> 6;                  // = group_waves(S): the launch made it so
+        gs.block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        gs.nparts = (uint32_t)(S * S) / gs.blocks;
+        gs.part = blockIdx.x % gs.nparts;             // workgroups of a tile are consecutive
+    }
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], gr[2], gg[2], gb[2];
     bool tiny = false, small = false;
@@ -547,7 +609,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Tf[j] = 1.0f; Ts[j] = 0.0f; nstop[j] = len; }
         auto forward_step = [&](const Rec &R, uint32_t idx) {
-            const uint32_t bf = block_flags<ATOMIC>(R_flags(R), w.flag_shift);
+            const uint32_t bf = block_flags<MODE != kOneBlock>(R_flags(R), w.flag_shift);
             const bool low[2] = {(bf & kLowTop) != 0, (bf & kLowBottom) != 0};
             const float o = R_o(R);
             const float dx = R_gx(R) - pxf;
@@ -600,7 +662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const bool inside = w.vx && (w.y0 + 4 * j) < w.ylim;
             if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
-        bwd_sweep<true, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, 1.0f, pairgrad);
+        bwd_sweep<true, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, 1.0f, pairgrad, gs);
     } else {
         // Between kTinyT and the smallest normal number the plain sweep still works on a transmittance
         // scaled by a power of two (exact): everything the sweep accumulates is linear in T, so the sums
@@ -611,7 +673,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int h = 0; h < 2; ++h) T[h] = T[h] * splat(kRescue);
             unscale = 1.0f / kRescue;
         }
-        bwd_sweep<false, ATOMIC>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, unscale, pairgrad);
+        bwd_sweep<false, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, unscale, pairgrad, gs);
     }
 }
 
@@ -634,6 +696,12 @@ extern "C" int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile
     return gsr_check_launch("composite_fwd");
 }
 
+extern "C" uint32_t gsr_pairgrad_parts(int tile_length)
+{
+    const int S = (tile_length + 15) >> 4;
+    return (S > 1 && S <= 4) ? (uint32_t)(S * S / group_waves(S)) : 1u;
+}
+
 extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, const uint32_t *tile_order,
                                  const float *stream_rec, const float *final_T, const float *dimg, uint32_t num_pairs,
                                  float *pairgrad, void *stream)
@@ -652,12 +720,17 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
     const int S = (v.L + 15) >> 4;
     const unsigned waves = (unsigned)v.T * S * S;
     const dim3 grid(gsr_div_up(waves, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
-    if (S > 1) {
+    if (S > 4) {
         (void)hipMemsetAsync(pairgrad, 0, (size_t)num_pairs * GSR_PAIRGRAD_FLOATS * sizeof(float), (hipStream_t)stream);
-        hipLaunchKernelGGL((composite_bwd_kernel<true>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
+        hipLaunchKernelGGL((composite_bwd_kernel<kAtomic>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
                            stream_rec, final_T, dimg, pairgrad);
+    } else if (S > 1) {
+        // S * S / group_waves(S) workgroups per tile, one wave per block of the tile
+        const int G = group_waves(S);
+        hipLaunchKernelGGL((composite_bwd_kernel<kTileGroup>), dim3((unsigned)v.T * (unsigned)(S * S / G)), dim3(64 * G), 0,
+                           (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, final_T, dimg, pairgrad);
     } else {
-        hipLaunchKernelGGL((composite_bwd_kernel<false>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
+        hipLaunchKernelGGL((composite_bwd_kernel<kOneBlock>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
                            stream_rec, final_T, dimg, pairgrad);
     }
     return gsr_check_launch("composite_bwd");

@@ -31,6 +31,8 @@ int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *
                              void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq,
                              uint32_t *overflow_flag /* bit 1 raised when the total does not fit 32 bits; may be null */);
 
+extern "C" uint32_t gsr_pairgrad_parts(int tile_length);
+
 static inline unsigned gsr_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // Tiles lo/L .. (hi-1)/L overlap the integer interval [lo, hi) when hi > lo, none otherwise.

@@ -356,7 +356,9 @@ __device__ inline void add_record(double (&acc)[9], const float *__restrict__ pa
 // (Walking the Gaussians in depth order, in which their records are consecutive in memory, was
 // measured slower than index order: the scattered 48-byte result rows cost more than the reads gain.)
 constexpr int kLanesPerGaussian = 4;   // (8 measured slower: 0.088 ms against 0.078 ms)
-__global__ __launch_bounds__(256) void pair_reduce_kernel(int n, const uint8_t *__restrict__ mask,
+// parts: rows of pairgrad per (tile, Gaussian) pair (gsr_pairgrad_parts): the rows of a Gaussian's pairs are
+// contiguous, parts * ntiles of them from row parts * slot_base, and are added in row order.
+__global__ __launch_bounds__(256) void pair_reduce_kernel(int n, uint32_t parts, const uint8_t *__restrict__ mask,
                                                           const uint32_t *__restrict__ slot_base,
                                                           const uint32_t *__restrict__ ntiles,
                                                           const float *__restrict__ pairgrad,
@@ -366,8 +368,8 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, const uint8_t *
     const int i = t / kLanesPerGaussian, q = t % kLanesPerGaussian;
     const int lane = threadIdx.x & 63;
     const bool live = i < n && mask[i];
-    const uint32_t nt = live ? ntiles[i] : 0u;
-    const uint32_t e0 = live ? slot_base[i] : 0u;
+    const uint32_t nt = live ? ntiles[i] * parts : 0u;
+    const uint32_t e0 = live ? slot_base[i] * parts : 0u;
     double acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
@@ -771,14 +773,15 @@ extern "C" size_t gsr_preprocess_bwd_workspace_bytes(uint32_t n)
     return ((size_t)(n ? n : 1) * 12 * sizeof(float) + 255) & ~(size_t)255;
 }
 
-extern "C" int gsr_pair_reduce(uint32_t n, const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
-                               const float *pairgrad, float *gsum, void *stream)
+extern "C" int gsr_pair_reduce(uint32_t n, uint32_t parts, const uint8_t *mask, const uint32_t *slot_base,
+                               const uint32_t *ntiles, const float *pairgrad, float *gsum, void *stream)
 {
     if (n == 0) return GSR_OK;
+    if (parts == 0 || parts > 4) { gsr_set_error("gsr_pair_reduce: %u rows per pair (1..4 expected)", parts); return GSR_ERR_ARG; }
     if (!mask || !slot_base || !ntiles || !gsum) { gsr_set_error("gsr_pair_reduce: null pointer"); return GSR_ERR_ARG; }
     if ((unsigned long long)n * kLanesPerGaussian >= (1ull << 31)) { gsr_set_error("gsr_pair_reduce: too many Gaussians"); return GSR_ERR_ARG; }
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(gsr_div_up(n * kLanesPerGaussian, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (int)n, mask, slot_base, ntiles, pairgrad, gsum);
+                       (int)n, parts, mask, slot_base, ntiles, pairgrad, gsum);
     return gsr_check_launch("pair_reduce");
 }
 
@@ -856,7 +859,7 @@ extern "C" int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords
     }
     if (v.n == 0) return GSR_OK;
     float *gsum = (float *)workspace;
-    if (int e = gsr_pair_reduce((uint32_t)v.n, mask, slot_base, ntiles, pairgrad, gsum, stream)) return e;
+    if (int e = gsr_pair_reduce((uint32_t)v.n, gsr_pairgrad_parts(v.L), mask, slot_base, ntiles, pairgrad, gsum, stream)) return e;
     const float *gsum_c = gsum;
     return gsr_preprocess_bwd_views(view_host, 1, coords, scale_raw, rot_raw, opac_raw, sh, &mask, &gsum_c, g_coords,
                                     g_scale, g_rot, g_opac, g_sh, &g_screen, nullptr, accumulate, stream);

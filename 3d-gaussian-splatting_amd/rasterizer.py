@@ -259,6 +259,12 @@ def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, vi
     return forward_finish(forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view))
 
 
+def _alloc_pairgrad(lib, st: RenderState, dev) -> torch.Tensor:
+    """The gradient records of a view: one row per (tile, Gaussian) pair and per workgroup of the pair's tile."""
+    rows = max(st.num_pairs, 1) * int(lib.gsr_pairgrad_parts(st.view.tile_length))
+    return torch.empty(rows, _lib.PAIRGRAD_FLOATS, dtype=torch.float32, device=dev)
+
+
 def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh, dimg, accumulate_into=None,
                       overwrite=False):
     """Compositing backward + stage-1 backward.  Returns the six dense gradients
@@ -272,7 +278,7 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     f32 = dict(dtype=torch.float32, device=dev)
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
-    pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
+    pairgrad = _alloc_pairgrad(lib, st, dev)
     _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T),
                                      _ptr(dimg), I, _ptr(pairgrad), stream)
     st.pairgrad = pairgrad
@@ -302,11 +308,11 @@ def backward_records(st: RenderState, dimg) -> torch.Tensor:
     f32 = dict(dtype=torch.float32, device=dev)
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
-    pairgrad = torch.empty(max(I, 1), _lib.PAIRGRAD_FLOATS, **f32)
+    pairgrad = _alloc_pairgrad(lib, st, dev)
     _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
     gsum = torch.empty(st.n, 12, **f32)
-    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, _ptr(st.mask_u8), _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad),
-          _ptr(gsum), stream)
+    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, int(lib.gsr_pairgrad_parts(st.view.tile_length)), _ptr(st.mask_u8),
+          _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad), _ptr(gsum), stream)
     return gsum
 
 

@@ -95,8 +95,9 @@ int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const flo
                        float *rec, gsr_counters *counters, void *stream);
 
 /* Backward of stage 1.  Replaces the autograd graph of the statements listed above
- * (Trainer.py:57).  pairgrad[I,12] holds one gradient record per (tile, Gaussian) pair at the
- * pair's emission slot: Gaussian g owns the contiguous slots slot_base[g] .. slot_base[g]+ntiles[g].
+ * (Trainer.py:57).  pairgrad (written by gsr_composite_bwd for the same view) holds the gradient records of
+ * the (tile, Gaussian) pairs at their emission slots: Gaussian g owns the contiguous slots
+ * slot_base[g] .. slot_base[g]+ntiles[g], gsr_pairgrad_parts(tile_length) rows each.
  * A Gaussian's records are summed in a fixed order, so the result is reproducible run to run.
  * Writes (or, with accumulate != 0, adds to) the dense gradients of the raw parameters
  * g_coords[N,3] g_scale[N,3] g_rot[N,4] g_opac[N] g_sh[N,3,16], and always overwrites
@@ -114,15 +115,16 @@ int gsr_preprocess_bwd(const gsr_view *view_host, const float *coords, const flo
 /* The two halves of gsr_preprocess_bwd, for view minibatches (the reference renders one view per
  * optimiser step, Trainer.py:52-57; a minibatch sums the gradients of several renders of the same
  * parameters).  gsr_pair_reduce sums one view's gradient records per Gaussian into gsum[N,12]
- * (the nine sums of a record; floats 9..11 are 0).  gsr_preprocess_bwd_views then chains the sums of
+ * (the nine sums of a record; floats 9..11 are 0); parts = gsr_pairgrad_parts(tile_length) of the
+ * view whose compositing backward wrote pairgrad.  gsr_preprocess_bwd_views then chains the sums of
  * num_views views (host arrays of per-view device pointers) to the raw parameters in one pass: the
  * dense gradients are written (accumulate == 0) or added to (accumulate != 0) ONCE for all views,
  * where per-view calls of gsr_preprocess_bwd re-read and re-write them for every view.
  * g_screen_host[v][N,3] receives view v's screen_coords gradient.  All views must share n and
  * sh_degree.  At most GSR_MAX_VIEWS views go into one kernel launch; more are processed in groups. */
 #define GSR_MAX_VIEWS 8
-int gsr_pair_reduce(uint32_t n, const uint8_t *mask, const uint32_t *slot_base, const uint32_t *ntiles,
-                    const float *pairgrad, float *gsum, void *stream);
+int gsr_pair_reduce(uint32_t n, uint32_t parts, const uint8_t *mask, const uint32_t *slot_base,
+                    const uint32_t *ntiles, const float *pairgrad, float *gsum, void *stream);
 int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num_views, const float *coords,
                              const float *scale_raw, const float *rot_raw, const float *opac_raw,
                              const float *sh, const uint8_t *const *mask_host, const float *const *gsum_host,
@@ -220,8 +222,14 @@ int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets, c
                       const float *stream_rec, float *img, float *final_T, void *stream);
 
 /* Backward of the blend (autograd of the statements above).  dimg[W,H,3] is dL/dimg.
- * pairgrad[I,12] is fully overwritten; the record of the pair at sorted position p goes to the row
- * named by its stream record's slot field (= pair_slot[p]). */
+ * pairgrad[I * parts, 12], parts = gsr_pairgrad_parts(tile_length), is fully overwritten: the pair at sorted
+ * position p with emission slot s (its stream record's slot field, = pair_slot[p]) owns the rows
+ * parts * s .. parts * s + parts - 1, whose sum is its gradient record.  parts is 1 when a tile is one 16x16
+ * block (tile_length <= 16) and 1, 3 or 4 for tiles of 4, 9 or 16 blocks (the reference's default tile edge
+ * of 64, GaussianRenderer.py:49, has 16): the blocks of such a tile are composited by `parts` workgroups, each
+ * of which adds its blocks' sums in a fixed order and stores its own row, so the gradients are reproducible
+ * run to run.  Only tiles of more than 16 blocks (tile_length > 64) use float atomics (parts = 1). */
+uint32_t gsr_pairgrad_parts(int tile_length);
 int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, const uint32_t *tile_order,
                       const float *stream_rec, const float *final_T, const float *dimg,
                       uint32_t num_pairs, float *pairgrad, void *stream);
