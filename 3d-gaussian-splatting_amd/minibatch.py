@@ -79,6 +79,24 @@ def _front_stream(dev):
     return _front_streams[key]
 
 
+def reserve_streams(device=None):
+    """Creates the two side streams of the pipelined minibatch (front part of the next views, counter read-back)
+    and runs a trivial operation on each, which binds them to hardware queues of their own.
+
+    Call this BEFORE ``torch.distributed.init_process_group("nccl", ...)``.  A process has few hardware queues
+    (``GPU_MAX_HW_QUEUES``, 4 by default) and HIP hands them to streams in the order the streams are first used;
+    RCCL takes its share when the process group is initialised.  Side streams first used after that end up on the
+    queue of the stream they are meant to run beside, and everything ``render_views`` enqueues is then executed one
+    kernel after the other: measured on the headline workload, 15.1 ms per step instead of 13.5 with nothing else
+    changed.  (Raising ``GPU_MAX_HW_QUEUES`` to 8 before the first HIP call has the same effect.)"""
+    from . import rasterizer as R
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    for stream in (_front_stream(dev), R._copy_stream(dev)):
+        with torch.cuda.stream(stream):
+            torch.zeros(1, device=dev).add_(1.0)
+    torch.cuda.synchronize(dev)
+
+
 def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Optional[Callable], grads=None,
                  accumulate: bool = False, overlap: bool = True, lookahead: int = 2, g_colors=None):
     """Forward + backward of the views of one rank against the same parameters, software-pipelined over

@@ -129,7 +129,11 @@ class MinibatchTrainer(Trainer):
     radius of every Gaussian over the step's views (the reference tests the radius in its one view,
     ``Trainer.py:68``).  The split's random draws come from a generator seeded with ``seed`` and the step
     number, so all ranks draw the same; parameters, optimiser state and sizes stay identical on all ranks
-    without ever being broadcast."""
+    without ever being broadcast.
+
+    Call ``minibatch.reserve_streams()`` before ``torch.distributed.init_process_group``: the views of a rank are
+    pipelined over two HIP streams, which have to be on hardware queues of their own (RCCL takes queues when the
+    group is initialised).  Gradients are bit-reproducible run to run for tile edges up to 64."""
 
     def __init__(self, model, dataloader, views_per_step: int = 8, group=None, seed: int = 0, **kwargs):
         super().__init__(model, dataloader, **kwargs)

@@ -18,6 +18,13 @@ import os
 import sys
 import time
 
+# The view minibatch is pipelined over two HIP streams and the counter read-back uses a third; with RCCL's own
+# streams a process runs out of HIP's default of 4 hardware queues, and streams that share a queue execute one
+# after the other.  main() therefore binds the side streams to queues before the process group exists
+# (gsplat_amd.minibatch.reserve_streams); where the environment leaves the number of queues open, ask for 8
+# (must happen before the first HIP call).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -27,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 import gsplat_amd  # noqa: E402,F401
 from gsplat_amd.camera import Camera  # noqa: E402
-from gsplat_amd.minibatch import GradBucket, reduce_gradients, render_views, shard_views  # noqa: E402
+from gsplat_amd.minibatch import GradBucket, reduce_gradients, render_views, reserve_streams, shard_views  # noqa: E402
 from gsplat_amd.loss import loss_and_grad  # noqa: E402
 from gsplat_amd.rasterizer import StageTimer, ViewSpec, sh_grad_views  # noqa: E402
 from gsplat_amd.scenes import synthetic_scene  # noqa: E402
@@ -48,17 +55,31 @@ def minibatch_cameras(scene, n_views, device):
     return cams
 
 
-def algorithmic_bytes(n, m, pairs, pixels, k_sh):
-    """Compulsory HBM bytes per view of each stage: n Gaussians (m visible) with 236-byte parameter rows
-    and 64-byte per-Gaussian outputs, `pairs` (tile, Gaussian) pairs at 44 bytes per compositing read,
-    `pixels` pixels, k_sh active SH coefficients per channel."""
+def algorithmic_bytes(n, m, pairs, pixels, k_sh, views=1, parts=1):
+    """Compulsory HBM bytes of each stage: n Gaussians (m visible) with 236-byte parameter rows and 64-byte
+    per-Gaussian outputs, `pairs` (tile, Gaussian) pairs at 44 bytes per compositing read, `pixels` pixels,
+    k_sh active SH coefficients per channel.  All per view, except "preprocess_bwd_views": ONE launch chains the
+    per-Gaussian sums of `views` views to the raw parameters - it reads the parameters and writes the dense
+    gradients once per step, and reads 48 bytes of sums + the mask and writes the 12-byte screen gradient per view.
+    "pair_reduce" reads the per-pair gradient records (48 bytes, `parts` rows per pair) and writes the sums."""
     return {
         "preprocess_fwd": n * (12 + 12 + 16 + 4 + 12 * k_sh) + n + m * 64,
         "binning_sort": m * 16 + pairs * 12 + 2 * pairs * 12 + pairs * 8,
         "composite_fwd": pairs * (4 + 40) + pixels * 12 + pixels * 4,
         "composite_bwd": pairs * 44 + pixels * (12 + 12 + 8) + m * 40,
-        "preprocess_bwd": m * 40 + n * (44 + 12 * k_sh) + n * (44 + 192) + n * 12,
+        "pair_reduce": pairs * parts * 48 + n * 9 + n * 48,
+        "preprocess_bwd_views": n * (44 + 12 * k_sh) + n * 236 + views * n * (48 + 1 + 12),
     }
+
+
+def executed_flops_bwd(stream_rec, num_pairs):
+    """Flops the compositing backward EXECUTES for one view at tile 16, from the hint flags of its record stream:
+    a half block (128 pixels) whose alpha is pinned at 0.01 takes the short path (transmittance, suffix and colour
+    sums: about 20 flop per pixel), any other half the full one (about 60 flop per pixel and one exp2 + one rcp)."""
+    flags = stream_rec[:num_pairs].view(torch.int32)[:, 11] & 3
+    low_halves = int(((flags & 1) + ((flags >> 1) & 1)).sum().item())
+    full_halves = 2 * num_pairs - low_halves
+    return 128.0 * (60.0 * full_halves + 20.0 * low_halves), low_halves / max(2 * num_pairs, 1)
 
 
 def main():
@@ -111,6 +132,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the render path has no CPU implementation)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    reserve_streams(dev)       # before RCCL takes hardware queues
     if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.views % world != 0:
@@ -169,6 +191,8 @@ def main():
                                             g_colors=g_colors)
         if states and "m" not in stats:
             stats.update(m=states[0].num_visible, pairs=states[0].num_pairs)
+            if states[0].num_visible and args.tile <= 16 and not args.forward_only:
+                stats["executed"] = executed_flops_bwd(states[0].stream_rec, states[0].num_pairs)
         if args.forward_only:
             return
         if g_colors is not None:
@@ -237,7 +261,10 @@ def main():
         value = renders / elapsed
         pixels = args.width * args.height
         k_sh = (args.sh_degree + 1) ** 2
-        ab = algorithmic_bytes(n, stats.get("m", n), stats.get("pairs", 0), pixels, k_sh)
+        import ctypes
+        from gsplat_amd import _lib as gsr_lib
+        parts = int(gsr_lib.load().gsr_pairgrad_parts(ctypes.c_int(args.tile)))
+        ab = algorithmic_bytes(n, stats.get("m", n), stats.get("pairs", 0), pixels, k_sh, views=max(len(views), 1), parts=parts)
         # device time of each stage per rendered view of this rank (the chain to the raw parameters runs
         # once per step for all views of the rank; pair_reduce + preprocess_bwd_views = stage-1 backward)
         views_timed = max(len(views), 1) * breakdown_steps
@@ -247,12 +274,15 @@ def main():
         dom_ms = total_ms / max(calls, 1)      # average launch duration over the timed region
         dom_alone_ms = stage_ms.get(dom)
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM-side bytes of one launch from the PMC passes under profiles/ - reported only when they were taken
+        # on this workload's own first view (same pair count), otherwise null
+        traffic = traffic_pairs = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            key = f"{n}_{args.width}x{args.height}_t{args.tile}_deg{args.sh_degree}"
-            traffic = tj.get(key, {}).get(dom)
+            tj = json.load(open(tfile)).get(f"{n}_{args.width}x{args.height}_t{args.tile}_deg{args.sh_degree}", {})
+            if tj.get("pairs") == stats.get("pairs"):
+                traffic = tj.get("kernels", {}).get(dom, {}).get("total")
+                traffic_pairs = tj.get("pairs")
         pairs = stats.get("pairs", 0)
         flops_bwd = 60.0 * pairs * 256.0 if args.tile == 16 else None
         out = {
@@ -283,23 +313,31 @@ def main():
             "roofline": {
                 "kernel": dom + "_kernel", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_measured_at_pairs": traffic_pairs,
                 "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": round(dom_ms, 4),
                 "avg_launch_ms_alone": None if dom_alone_ms is None else round(dom_alone_ms, 4),
-                "note": "compositing is bound by the vector ALU and the CU's shared scalar unit at these list lengths, not by HBM; "
-                        "traffic = HBM-side bytes of one launch from the PMC passes under profiles/; avg_launch_ms is measured in "
+                "note": "compositing is bound by vector instruction issue at these list lengths (SQ counters: profiles/r02a_pmc_composite_sq.txt), not by HBM; "
+                        "traffic = HBM-side bytes of one launch of this kernel on this workload's first view from the PMC passes under profiles/ (traffic.json); avg_launch_ms is measured in "
                         "the timed region, where the next view's stage 1, sorts and lists run beside the kernel on a second "
                         "stream and share the CUs with it (avg_launch_ms_alone: the same launch with nothing beside it)",
             },
             "stage_ms_per_view": {k: round(v, 4) for k, v in stage_ms.items()},
             "exchange_ms_per_step": None if exchange_ms is None else round(exchange_ms, 4),
-            "stage_hbm_frac": {k: round(ab[a] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                               for k, a in (("preprocess_fwd", "preprocess_fwd"), ("composite_fwd", "composite_fwd"),
-                                            ("composite_bwd", "composite_bwd"), ("preprocess_bwd", "preprocess_bwd"))
-                               if stage_ms.get(k, 0.0) > 0.0},
+            # algorithmic bytes of a stage / its device time alone / 8 TB/s.  preprocess_bwd_views is ONE launch per
+            # step for all views of the rank: its bytes and its time are both per step
+            "stage_hbm_frac": dict(
+                [(k, round(ab[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                 for k in ("preprocess_fwd", "composite_fwd", "composite_bwd", "pair_reduce") if stage_ms.get(k, 0.0) > 0.0] +
+                [("preprocess_bwd_views", round(ab["preprocess_bwd_views"] / (stage_ms["preprocess_bwd_views"] * max(len(views), 1) * 1e-3)
+                                                / 1e9 / HBM_PEAK_GBS, 4))] if stage_ms.get("preprocess_bwd_views", 0.0) > 0.0 else []),
         }
         if flops_bwd and not args.forward_only:
+            # 60 flop for every pixel of every pair (what the reference's formulation costs) ...
             out["roofline"]["valu_frac_algorithmic"] = round(flops_bwd / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)
+            if "executed" in stats:
+                # ... and the flops the kernel executes: halves of a block on which alpha is pinned at 0.01 take a short path
+                out["roofline"]["valu_frac_executed"] = round(stats["executed"][0] / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)
+                out["roofline"]["low_half_fraction"] = round(stats["executed"][1], 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cams, args)
         print(json.dumps(out))

@@ -22,11 +22,14 @@ def _scan_both(L, lib, x):
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     L.check(lib.gsr_exclusive_scan(tin.data_ptr(), out_ws.data_ptr(), n, tot_ws.data_ptr(), ws.data_ptr(), wsb, stream), "scan")
     torch.cuda.synchronize()
-    # neither torch's allocator nor the device's free memory (a raw hipMalloc) may move
-    before = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev), torch.cuda.mem_get_info(dev)[0])
+    # torch's allocator must not move, and the device's free memory must not shrink (a raw hipMalloc would take
+    # some; it may grow: child processes of earlier tests can still be giving their memory back)
+    before = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev))
+    free_before = torch.cuda.mem_get_info(dev)[0]
     L.check(lib.gsr_exclusive_scan_static(tin.data_ptr(), out_st.data_ptr(), n, tot_st.data_ptr(), stream), "scan_static")
     torch.cuda.synchronize()
-    assert (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev), torch.cuda.mem_get_info(dev)[0]) == before
+    assert (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)) == before
+    assert torch.cuda.mem_get_info(dev)[0] >= free_before
     return out_ws.cpu().numpy()[:n], int(tot_ws.cpu()[0]), out_st.cpu().numpy()[:n], int(tot_st.cpu()[0])
 
 

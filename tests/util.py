@@ -59,18 +59,19 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
 
 
-def assert_close(got, ref, name="", rtol=RTOL, atol_frac=ATOL_FRAC, outlier_frac=0.0, outlier_rtol=0.0,
+def assert_close(got, ref, name="", rtol=RTOL, atol_frac=ATOL_FRAC, outlier_rows=None, outlier_rtol=0.0,
                  outlier_atol_frac=0.0):
     """|got - ref| <= rtol*|ref| + atol_frac*max|ref| for every element.
 
-    ``outlier_frac`` > 0 lets that fraction of the elements miss the bound, provided they still meet
-    the looser ``outlier_rtol`` / ``outlier_atol_frac`` bound.  It exists for one documented reason.
+    ``outlier_rows`` = (k, f) lets the elements of at most max(k, f * rows) ROWS (first axis: Gaussians) miss the
+    bound, provided they still meet the looser ``outlier_rtol`` / ``outlier_atol_frac`` bound.  It exists for one
+    documented reason, and test_every_gradient_outlier_sits_on_a_clamp_threshold measures it (none of 200 k
+    Gaussians at 800x800, 3 of a million at 1080p, each of them a Gaussian the oracle itself moves).
     alpha = clamp(opacity*G, 0.01, 0.99) passes gradient only inside the interval, so a pixel whose
     opacity*G lies within one ulp of 0.01 is a DISCRETE decision, and two correct fp32 evaluations
     of G (the GPU's exp2 of a pre-scaled exponent, the CPU's expf) can decide it differently.  A
     render at 1 M Gaussians / 1080p evaluates 1.4e9 pixel-Gaussian pairs and a handful of them sit
-    that close to the threshold (measured: 3 Gaussians, relative distance 2e-7..7e-7,
-    tools/diag_flags.py); for a sharp splat that passes ~20 pixels one such pixel is worth ~1 % of
+    that close to the threshold; for a sharp splat that passes ~20 pixels one such pixel is worth ~1 % of
     its position gradient.  Rounding noise proper is ~1e-7 of max|ref| and needs no allowance.
     """
     got = np.asarray(got, dtype=np.float64)
@@ -89,19 +90,21 @@ def assert_close(got, ref, name="", rtol=RTOL, atol_frac=ATOL_FRAC, outlier_frac
     tol = rtol * np.abs(ref) + atol_frac * scale
     err = np.abs(got - ref)
     bad = err > tol
-    allowed = int(np.ceil(outlier_frac * bad.size)) if outlier_frac > 0 else 0
+    rows = bad.shape[0] if bad.ndim else 1
+    bad_rows = int(bad.reshape(rows, -1).any(axis=1).sum()) if bad.size else 0
+    allowed = max(int(outlier_rows[0]), int(np.ceil(outlier_rows[1] * rows))) if outlier_rows else 0
     worse = err > np.maximum(tol, outlier_rtol * np.abs(ref) + outlier_atol_frac * scale)
-    if int(bad.sum()) > allowed or worse.any():
+    if bad_rows > allowed or worse.any():
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(
-            f"{name}: {int(bad.sum())}/{bad.size} elements outside rtol={rtol} (+{atol_frac}*max), {allowed} allowed, "
+            f"{name}: {int(bad.sum())}/{bad.size} elements in {bad_rows} rows outside rtol={rtol} (+{atol_frac}*max), {allowed} rows allowed, "
             f"{int(worse.sum())} beyond the outlier bound; worst at {i}: "
             f"got {got[i]!r} ref {ref[i]!r} err {err[i]:.3e} tol {tol[i]:.3e} (max|ref|={scale:.3e})")
 
 
-# Gradients compared across devices: at most 2 in 100 000 elements may differ by a clamp-threshold
-# pixel (see assert_close), and then by no more than a few per cent of the element.
-GRAD_OUTLIERS = dict(outlier_frac=2e-5, outlier_rtol=0.05, outlier_atol_frac=2e-3)
+# Gradients compared across devices: the gradients of at most 2 Gaussians, or 4 in a million, may differ by a
+# clamp-threshold pixel (see assert_close), and then by no more than a few per cent of the element.
+GRAD_OUTLIERS = dict(outlier_rows=(2, 4e-6), outlier_rtol=0.05, outlier_atol_frac=2e-3)
 
 
 def assert_bit_equal(got, ref, name=""):

@@ -6,12 +6,19 @@ gradient exchange, densification statistics, densification at iteration 50, remo
         tools/two_rank_trainer.py --out gpurun_out/mbt_rank
     python tools/two_rank_trainer.py --compare gpurun_out/mbt_single.npz gpurun_out/mbt_rank0.npz gpurun_out/mbt_rank1.npz
 
-(RCCL refuses two ranks on one device, hence gloo; the collectives' semantics are the same.
-tests/test_zy_two_rank_trainer.py runs these three commands as child processes.)
+(RCCL refuses two ranks on one device, hence gloo; the collectives' semantics are the same, and they run on the
+device tensors as the trainer issues them.  tests/test_zy_two_rank_trainer.py runs these three commands as child
+processes.)
 """
 import argparse
 import os
 import sys
+
+# Two processes on one GPU, each with the trainer's three streams and gloo's own: with HIP's default of 4 hardware
+# queues per process, streams share queues and a device-tensor collective of gloo eventually waits for ever (seen
+# once per run: 39 collectives in, both ranks inside the same all_gather_into_tensor); with 16 queues 686
+# collectives over 60 iterations all return.  Must be set before the first HIP call.
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("GSR_TWO_RANK_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -32,7 +39,7 @@ class RingLoader:
         return self.cams[self.k], self.targets[self.k]
 
 
-def run(out, steps, views):
+def run(out, steps, views, staged=False, trace=False, sync_before=False, watchdog=240):
     import torch.distributed as dist
     import gsplat_amd  # noqa: F401
     from gsplat_amd.camera import Camera
@@ -43,9 +50,11 @@ def run(out, steps, views):
     import faulthandler
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    faulthandler.dump_traceback_later(240, exit=True)      # a collective that never returns names itself
+    faulthandler.dump_traceback_later(watchdog, exit=True)      # a collective that never returns names itself
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    from gsplat_amd.minibatch import reserve_streams
+    reserve_streams(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,10 +63,24 @@ def run(out, steps, views):
         gathered = torch.empty(2 * world, device=dev)
         dist.all_gather_into_tensor(gathered, probe[:2].contiguous())
         print(f"rank {rank}: collectives on device tensors work: {probe.tolist()} {gathered.tolist()}", flush=True)
-        # gloo's collectives on device tensors sometimes never return on this image (a different one from
-        # run to run; small ones like those above do return): stage them through host memory here.  RCCL,
-        # which the trainer uses with one GPU per rank, works on device tensors natively.
         gather, reduce = dist.all_gather_into_tensor, dist.all_reduce
+        calls = [0]
+
+        def traced(name, fn):
+            # --trace: every collective is announced before and after, so a call that never returns is the last line
+            def call(*a, **kw):
+                calls[0] += 1
+                t = a[0]
+                if trace:
+                    print(f"rank {rank}: #{calls[0]} {name} {tuple(t.shape)} {t.dtype} on {t.device}, stream "
+                          f"{torch.cuda.current_stream().cuda_stream:#x} ...", flush=True)
+                if sync_before:
+                    torch.cuda.current_stream().synchronize()
+                r = fn(*a, **kw)
+                if trace:
+                    print(f"rank {rank}: #{calls[0]} {name} returned", flush=True)
+                return r
+            return call
 
         def staged_gather(out, inp, group=None):
             host = torch.empty(out.shape, dtype=out.dtype)
@@ -69,7 +92,10 @@ def run(out, steps, views):
             reduce(host, op=op, group=group)
             t.copy_(host)
 
-        dist.all_gather_into_tensor, dist.all_reduce = staged_gather, staged_reduce
+        if staged:       # fallback: the collectives on host copies
+            dist.all_gather_into_tensor, dist.all_reduce = staged_gather, staged_reduce
+        elif trace or sync_before:
+            dist.all_gather_into_tensor, dist.all_reduce = traced("all_gather_into_tensor", gather), traced("all_reduce", reduce)
     sc = synthetic_scene(3000, 128, 96, 1, seed=8)
     p = [t.to(dev) for t in sc.params()]
     cams = []
@@ -151,11 +177,15 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--compare", nargs=3, metavar=("SINGLE", "RANK0", "RANK1"))
+    ap.add_argument("--staged", action="store_true", help="run the collectives on host copies of the tensors")
+    ap.add_argument("--trace", action="store_true", help="announce every collective before and after")
+    ap.add_argument("--sync-before", action="store_true", help="synchronise the stream before each collective")
+    ap.add_argument("--watchdog", type=int, default=240, help="seconds until a stuck run dumps its Python stacks and exits")
     args = ap.parse_args()
     if args.compare:
         compare(*args.compare)
     else:
-        run(args.out, args.steps, args.views)
+        run(args.out, args.steps, args.views, args.staged, args.trace, args.sync_before, args.watchdog)
 
 
 if __name__ == "__main__":
