@@ -208,30 +208,28 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     float sink = 0.0f;
     if (w.begin < w.end) {
         // Two record buffers, alternating: while one is blended the other is in flight.  All stream
-        // positions are 32-bit byte offsets (64 bytes per record).
+        // positions are 32-bit byte offsets (64 bytes per record).  Two entries per turn and ONE exit, an odd
+        // last entry after the loop: with an exit between the two entries as well, the compiler copied all
+        // sixteen accumulator registers twice per turn (a quarter of the loop's vector instructions).
         const uint32_t off_last = (w.end - 1) * 64u;
         const uint32_t off_stream_last = (w.total - 1) * 64u;   // the touches may run into the next lists
         const uint32_t touch_floor = min(64u, off_stream_last);
         uint32_t off = w.begin * 64u;
+        const uint32_t n = w.end - w.begin;
         Rec A, B;
         rec_request(stream_rec, off, A);
-        for (;;) {
+        for (uint32_t i = n >> 1; i != 0; --i) {
             rec_wait(A);
-            uint32_t next = min(off + 64u, off_last);
-            rec_request(stream_rec, next, B);
+            rec_request(stream_rec, off + 64u, B);
             l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor), touch_off, sink);
             blend(A);
-            if (off == off_last) break;
-            off = next;
             rec_wait(B);
-            next = min(off + 64u, off_last);
-            rec_request(stream_rec, next, A);
+            rec_request(stream_rec, min(off + 128u, off_last), A);   // (the last record again after the last pair)
             blend(B);
-            if (off == off_last) break;
-            off = next;
+            off += 128u;
         }
-        rec_wait(A);   // nothing may be in flight when the wave ends
-        rec_wait(B);
+        rec_wait(A);
+        if (n & 1u) blend(A);
         l2_touch_drain(sink);
     }
     if (!w.vx) return;
@@ -523,29 +521,29 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     const uint32_t touch_off = ((threadIdx.x & 1) && w.total > 1u) ? 64u : 0u;
     float sink = 0.0f;
     Rec A, B;
+    const uint32_t n = w.end - w.begin;
     rec_request(stream_rec, off, A);
-    for (;;) {
+    // two entries per turn and a single exit: the registers of the running sums stay put (a loop that can also
+    // end between the two entries made the compiler copy all of them twice per turn)
+    for (uint32_t i = n >> 1; i != 0; --i) {
         rec_wait(A);
-        uint32_t next = max(off, off_first + 64u) - 64u;
-        rec_request(stream_rec, next, B);
+        rec_request(stream_rec, off - 64u, B);
         // the two lines below the one sixteen entries down (never below the start of the stream)
         l2_touch(stream_rec, max(off, (kTouchAhead + 1) * 64u) - (kTouchAhead + 1) * 64u, touch_off, sink);
         entry(A, k);
         if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
-        if (off == off_first) break;
-        off = next;
-        if (CHECK) --k;
         rec_wait(B);
-        next = max(off, off_first + 64u) - 64u;
-        rec_request(stream_rec, next, A);
-        entry(B, k);
+        rec_request(stream_rec, max(off, off_first + 128u) - 128u, A);   // (the first record again after the last pair)
+        entry(B, k - 1u);
         if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
-        if (off == off_first) break;
-        off = next;
-        if (CHECK) --k;
+        off -= 128u;
+        if (CHECK) k -= 2u;
     }
     rec_wait(A);
-    rec_wait(B);
+    if (n & 1u) {
+        entry(A, k);
+        if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
+    }
     l2_touch_drain(sink);
     // (every wave of a tile group walks the same list: the barriers inside the flushes match up)
     if (MODE == kTileGroup && gs.entry != 0) group_flush(gs, gs.entry, pairgrad);
@@ -636,25 +634,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             float sink = 0.0f;
             Rec A, B;
             rec_request(stream_rec, off, A);
-            for (;;) {
+            for (uint32_t i = len >> 1; i != 0; --i) {
                 rec_wait(A);
-                uint32_t next = min(off + 64u, off_last);
-                rec_request(stream_rec, next, B);
+                rec_request(stream_rec, off + 64u, B);
                 l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor), touch_off, sink);
                 forward_step(A, idx);
-                if (off == off_last) break;
-                off = next;
-                ++idx;
                 rec_wait(B);
-                next = min(off + 64u, off_last);
-                rec_request(stream_rec, next, A);
-                forward_step(B, idx);
-                if (off == off_last) break;
-                off = next;
-                ++idx;
+                rec_request(stream_rec, min(off + 128u, off_last), A);   // (the last record again after the last pair)
+                forward_step(B, idx + 1u);
+                off += 128u;
+                idx += 2u;
             }
             rec_wait(A);
-            rec_wait(B);
+            if (len & 1u) forward_step(A, idx);
             l2_touch_drain(sink);
         }
 #pragma unroll
