@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
         cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
         T[h] = T[h] * splat(1.0f - kAlphaMin);
+        asm("" : "+v"(T[h]));   // keeps this multiply here: merged with half_full's it needs its factor in registers
     };
     auto half_full = [&](int h, const Rec &R, float red, float o, float bdx, float adx2) {
         const f2 dy = splat(R_gy(R)) - pyf[h];
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     };
     auto blend = [&](const Rec &R) {
         const float red = R_r(R);
-        if (block_flags<MULTI>(R_flags(R), w.flag_shift) == kLowBoth) {
+        const uint32_t flags = block_flags<MULTI>(R_flags(R), w.flag_shift);
+        if (flags == kLowBoth) {
             half_low(0, R, red);
             half_low(1, R, red);
             return;
@@ -197,10 +199,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         const float dx = R_gx(R) - pxf;
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
-        // (treating a single clamped-low half separately only adds scalar work here: the forward
-        // loop is bound by the scalar unit, not by its arithmetic)
-        half_full(0, R, red, o, bdx, adx2);
-        half_full(1, R, red, o, bdx, adx2);
+        if (flags & kLowTop) half_low(0, R, red); else half_full(0, R, red, o, bdx, adx2);
+        if (flags & kLowBottom) half_low(1, R, red); else half_full(1, R, red, o, bdx, adx2);
     };
     // odd lanes touch the record before the one named (offset - 64, in wrapping 32-bit arithmetic); the
     // named record is never the stream's first one unless the stream has no other (touch_floor)
@@ -295,6 +295,7 @@ constexpr unsigned long long kColWriters = (0x7Full | (3ull << 10)) | (1ull << 2
 struct RecordLanes {
     uint32_t full_off, col_off;   // byte offset of the lane's float inside a record
     bool full_main, col_zero;     // the lane holds one of the 8 merged sums / writes a zero
+    float colour;                 // 1 on the six lanes that write a colour float of a full record (floats 6..11), else 0
 };
 __device__ inline RecordLanes record_lanes(int lane)
 {
@@ -303,6 +304,7 @@ __device__ inline RecordLanes record_lanes(int lane)
     L.full_off = 4u * (L.full_main ? (uint32_t)(lane >> 3) : 8u + (uint32_t)(lane >> 4));
     L.col_zero = lane < 6 || lane == 10 || lane == 11;
     L.col_off = 4u * (uint32_t)(lane & 15);
+    L.colour = (((kFullWriters >> lane) & 1ull) && L.full_off >= 24u) ? 1.0f : 0.0f;
     return L;
 }
 
@@ -376,9 +378,8 @@ __device__ inline void group_flush(GroupSlot &gs, uint32_t count, float *pairgra
 
 // Full record, floats: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2, dL/d(opacity),
 // dL/d(red), dL/d(green), then four partial sums of dL/d(blue).
-template <int MODE>
-__device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, uint32_t rec_off, const GroupSlot &gs, float unscale, float vx,
-                                         float vy, float xx, float xy, float yy, float o, float r, float g, float b)
+// Returns, on every writer lane of a full record, the float that lane stores (before any rescaling).
+__device__ inline float reduce_full(const RecordLanes &L, float vx, float vy, float xx, float xy, float yy, float o, float r, float g, float b)
 {
     // pairing order chosen so that group g of 8 lanes ends up with record float g
     const float m0 = merge_halves(vx, yy), m1 = merge_halves(xx, r), m2 = merge_halves(vy, o), m3 = merge_halves(xy, g);
@@ -386,7 +387,7 @@ __device__ inline void reduce_store_full(const RecordLanes &L, float *pairgrad, 
     const float n1 = merge_rows(m2, m3);   // rows: vy, xy, o,  g
     const float all8 = sum8(merge_half_rows(n0, n1));
     const float blue = sum16(b);
-    put_record<MODE>(pairgrad, rec_off, L.full_off, (L.full_main ? all8 : blue) * unscale, kFullWriters, gs);
+    return L.full_main ? all8 : blue;
 }
 
 // Colour-only record (the clamp blocks every other gradient of the entry).
@@ -409,12 +410,27 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     f2 suffix[2] = {splat(0.f), splat(0.f)};
     const f2 py_top = pyf[0];
     const RecordLanes lanes = record_lanes(threadIdx.x & 63);
+    // Plain sweep: the colour gradient of an entry that is clamped low on the whole block needs no sums.  With
+    // U_c(k) = sum over the block's pixels of T_k g_c (T_k: transmittance in front of entry k, g_c: the pixel's
+    // cotangent in channel c), every entry has  U_c(k) = U_c(k+1) + dL/dc_k  (T_k = T_{k+1} + alpha_k T_k, and
+    // dL/dc_k = sum alpha_k T_k g_c), and an entry with alpha = 0.01 everywhere has  dL/dc_k = 0.01 U_c(k) =
+    // (0.01 / 0.99) U_c(k+1).  U is kept on the six lanes that store the colour floats of a record (in the
+    // record's layout: red, green, four partial sums of blue over the rows of lanes) and follows from the sums
+    // every other entry reduces anyway.
+    const float low_gain = lanes.colour * (kAlphaMin / (1.0f - kAlphaMin));
+    const float low_gain_out = low_gain * unscale;
+    float U = 0.0f;
+    if (!CHECK) {
+        const f2 ur = pk_fma(T[1], gr[1], T[0] * gr[0]), ug = pk_fma(T[1], gg[1], T[0] * gg[0]), ub = pk_fma(T[1], gb[1], T[0] * gb[0]);
+        U = reduce_full(lanes, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, ur.x + ur.y, ug.x + ug.y, ub.x + ub.y) * lanes.colour;
+    }
     // Sums of one entry over the lane's pixels (pairs are added up at the end).
     f2 s_vx, s_vy, s_xx, s_xy, s_yy, s_o, s_r, s_g, s_b;
 
     // One half of the block with alpha = 0.01 on every pixel: only the transmittance recurrence, the
     // colour sums and the suffix remain; the clamp blocks every geometric gradient.
-    auto half_low = [&](int h, const Rec &R, uint32_t k, float red) {
+    // (`first`: the half is the first one of its entry to add to the colour sums - it sets them)
+    auto half_low = [&](int h, const Rec &R, uint32_t k, float red, const bool first, const bool with_colour) {
         const float om = 1.0f - kAlphaMin, rcp = 1.0f / (1.0f - kAlphaMin);
         const f2 t0 = T[h] * splat(rcp);
         f2 Tk = pk_fma(pk_fma(splat(-om), t0, T[h]), splat(rcp), t0);
@@ -432,11 +448,15 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         }
         T[h] = Tk;
         suffix[h] = suf;
-        s_r = pk_fma(wgt, gr[h], s_r);
-        s_g = pk_fma(wgt, gg[h], s_g);
-        s_b = pk_fma(wgt, gb[h], s_b);
+        if (with_colour) {
+            s_r = first ? wgt * gr[h] : pk_fma(wgt, gr[h], s_r);
+            s_g = first ? wgt * gg[h] : pk_fma(wgt, gg[h], s_g);
+            s_b = first ? wgt * gb[h] : pk_fma(wgt, gb[h], s_b);
+        }
     };
-    auto half_full = [&](int h, const Rec &R, uint32_t k, float red, float o, float dx, float adx2, float bdx) {
+    // (`first_geo`: the first half of its entry to add to the geometric sums)
+    auto half_full = [&](int h, const Rec &R, uint32_t k, float red, float o, float dx, float adx2, float bdx, const bool first,
+                         const bool first_geo) {
         const float cadx = R_ca(R) * dx;   // with v = conic * d:  v_x = a dx + bh dy,  v_y = bh dx + d dy
         const float cbdx = R_cbh(R) * dx;
         // bottom-half rows are the top-half rows + 8 (exact in fp32): one register pair less to keep
@@ -469,48 +489,59 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         }
         T[h] = Tk;
         suffix[h] = suf;
-        s_r = pk_fma(wgt, gr[h], s_r);
-        s_g = pk_fma(wgt, gg[h], s_g);
-        s_b = pk_fma(wgt, gb[h], s_b);
+        s_r = first ? wgt * gr[h] : pk_fma(wgt, gr[h], s_r);
+        s_g = first ? wgt * gg[h] : pk_fma(wgt, gg[h], s_g);
+        s_b = first ? wgt * gb[h] : pk_fma(wgt, gb[h], s_b);
         // clamp passes gradient on [0.01, 0.99]: exactly when the clamped value equals the input
         const bool p0 = (a.x == raw.x), p1 = (a.y == raw.y);
         const f2 d_raw = f2{p0 ? d_a.x : 0.0f, p1 ? d_a.y : 0.0f};
-        s_o = pk_fma(d_raw, G, s_o);
+        s_o = first_geo ? d_raw * G : pk_fma(d_raw, G, s_o);
         const f2 hh = d_raw * a;                       // = -2 dL/d(exponent); a == raw when it matters
         // Sums are taken in the conic-weighted coordinates v: summing h*d and weighting by the
         // conic afterwards would cancel large coherent sums for elongated Gaussians.
         const f2 vx = pk_fma(splat(R_cbh(R)), dy, splat(cadx));
         const f2 vy = pk_fma(splat(R_cd(R)), dy, splat(cbdx));
         const f2 hvx = hh * vx, hvy = hh * vy;
-        s_vx += hvx;
-        s_vy += hvy;
-        s_xx = pk_fma(hvx, vx, s_xx);
-        s_xy = pk_fma(hvx, vy, s_xy);
-        s_yy = pk_fma(hvy, vy, s_yy);
+        s_vx = first_geo ? hvx : s_vx + hvx;
+        s_vy = first_geo ? hvy : s_vy + hvy;
+        s_xx = first_geo ? hvx * vx : pk_fma(hvx, vx, s_xx);
+        s_xy = first_geo ? hvx * vy : pk_fma(hvx, vy, s_xy);
+        s_yy = first_geo ? hvy * vy : pk_fma(hvy, vy, s_yy);
     };
     auto entry = [&](const Rec &R, uint32_t k) {
         const uint32_t rec_off = R_slot(R) * (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));   // a Gaussian's records are contiguous
         const uint32_t flags = block_flags<MODE != kOneBlock>(R_flags(R), w.flag_shift);
-        const f2 z = splat(0.f);
-        s_r = s_g = s_b = z;
         const float red = R_r(R);
         if (flags == kLowBoth) {
-            half_low(0, R, k, red);
-            half_low(1, R, k, red);
-            reduce_store_colour<MODE>(lanes, pairgrad, rec_off, gs, unscale, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+            if (CHECK) {
+                half_low(0, R, k, red, true, true);
+                half_low(1, R, k, red, false, true);
+                reduce_store_colour<MODE>(lanes, pairgrad, rec_off, gs, unscale, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+            } else {
+                half_low(0, R, k, red, true, false);
+                half_low(1, R, k, red, false, false);
+                put_record<MODE>(pairgrad, rec_off, lanes.full_off, U * low_gain_out, kFullWriters, gs);   // zeros in floats 0..5
+                U = fmaf(U, low_gain, U);
+            }
             return;
         }
-        s_vx = s_vy = s_xx = s_xy = s_yy = s_o = z;
         const float o = R_o(R);
         const float dx = R_gx(R) - pxf;
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
-        if (flags & kLowTop) half_low(0, R, k, red); else half_full(0, R, k, red, o, dx, adx2, bdx);
-        if (flags & kLowBottom) half_low(1, R, k, red); else half_full(1, R, k, red, o, dx, adx2, bdx);
+        if (flags & kLowTop) {
+            half_low(0, R, k, red, true, true);
+            half_full(1, R, k, red, o, dx, adx2, bdx, false, true);   // (not both halves are flagged here)
+        } else {
+            half_full(0, R, k, red, o, dx, adx2, bdx, true, true);
+            if (flags & kLowBottom) half_low(1, R, k, red, false, true); else half_full(1, R, k, red, o, dx, adx2, bdx, false, false);
+        }
         // (an entry that is not flagged but whose clamp blocks every pixel anyway - one in a thousand -
         // simply stores zero sums)
-        reduce_store_full<MODE>(lanes, pairgrad, rec_off, gs, unscale, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y,
-                                  s_yy.x + s_yy.y, s_o.x + s_o.y, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+        const float val = reduce_full(lanes, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y, s_yy.x + s_yy.y, s_o.x + s_o.y,
+                                      s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+        if (!CHECK) U = fmaf(val, lanes.colour, U);
+        put_record<MODE>(pairgrad, rec_off, lanes.full_off, val * unscale, kFullWriters, gs);
     };
     // back to front, two record buffers alternating (see composite_fwd_kernel); k is only needed by
     // the checked variant
