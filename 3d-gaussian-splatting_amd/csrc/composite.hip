@@ -28,7 +28,7 @@ constexpr float kAlphaMax = 0.99f;
 // works for as long as the transmittance is a normal fp32 number with room below it for the exact
 // remainder of the correctly rounded quotient (2^-24 of it): kTinyT.  A wave whose smallest final
 // transmittance lies between the smallest normal number and kTinyT scales its transmittances up by
-// kRescue (a power of two, exact) and still takes the plain sweep.  Only a wave with a pixel whose
+// kRescue and its cotangents down by it (a power of two, exact) and still takes the plain sweep.  Only a wave with a pixel whose
 // transmittance went denormal or to zero takes the checked sweep (see composite_bwd_kernel), which
 // re-runs the forward recurrence, costs about two plain sweeps, and drops, per pixel, the entries
 // behind the point where the transmittance falls below kTinyT: their weights are below 1e-26 of the
@@ -115,16 +115,34 @@ __device__ inline void rec_request(const float *__restrict__ stream_rec, uint32_
 }
 __device__ inline void rec_wait(Rec &R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.d)::"memory"); }
 
+// A wave-uniform address as a pair of scalar registers.  Where the compiler does not see that a stream offset
+// is uniform it computes the address on the vector ALU and this reads it back with v_readfirstlane; where it
+// does, this costs nothing.
+__device__ inline const char *uniform_address(const char *p)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+}
+// A vector memory instruction must not read a scalar register within five wait states of a VECTOR instruction
+// (v_readfirstlane) writing it.  The compiler inserts those wait states for its own instructions but cannot see
+// into an asm statement, so every asm below whose memory instruction takes such an address starts with them.
+#define kSgprReady "s_nop 4\n\t"
+
 // Pulls the cache lines of records some entries further on into L2 with a vector load whose result
-// is never used (`lane_off` is 0 for even lanes and +64 or -64 for odd ones: a call touches two
-// neighbouring records, and one call per two entries touches every line of the stream).  The scalar record loads then
+// is never used (`lane_off` is 0 for half of the lanes and 64 for the others: a call touches two
+// neighbouring records, and one call per two entries touches every line of the stream; `off` is
+// wave-uniform and added to the base on the scalar unit).  The scalar record loads then
 // hit L2 instead of waiting for HBM; a wave has only one record in flight, so HBM latency would
 // otherwise bound the stream rate.  `sink` must stay live until the wave drains its vector loads
-// (l2_touch_drain).
+// (l2_touch_drain), and the drain must come before any code that follows the loop: the compiler counts the
+// register as written when the load is ISSUED, so once the loop is left it may move the value elsewhere and
+// reuse the register while a load is still on its way (tools/audit_touch.py checks the generated code).
 __device__ inline void l2_touch(const float *stream_rec, uint32_t off, uint32_t lane_off, float &sink)
 {
-    const uint32_t voff = lane_off + off;   // one VALU add; the base stays in SGPRs
-    asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(voff), "s"(stream_rec) : "memory");
+    const char *base = uniform_address(reinterpret_cast<const char *>(stream_rec) + off);
+    asm volatile(kSgprReady "global_load_dword %0, %1, %2" : "+v"(sink) : "v"(lane_off), "s"(base) : "memory");
 }
 __device__ inline void l2_touch_drain(float &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory"); }
 
@@ -202,9 +220,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         if (flags & kLowTop) half_low(0, R, red); else half_full(0, R, red, o, bdx, adx2);
         if (flags & kLowBottom) half_low(1, R, red); else half_full(1, R, red, o, bdx, adx2);
     };
-    // odd lanes touch the record before the one named (offset - 64, in wrapping 32-bit arithmetic); the
-    // named record is never the stream's first one unless the stream has no other (touch_floor)
-    const uint32_t touch_off = ((threadIdx.x & 1) && w.total > 1u) ? 0u - 64u : 0u;
+    // even lanes touch the record named, odd lanes the one before it; the named record is never the stream's
+    // first one unless the stream has no other (touch_floor)
+    const uint32_t touch_back = w.total > 1u ? 64u : 0u;
+    const uint32_t touch_off = (threadIdx.x & 1) ? 0u : touch_back;
     float sink = 0.0f;
     if (w.begin < w.end) {
         // Two record buffers, alternating: while one is blended the other is in flight.  All stream
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         for (uint32_t i = n >> 1; i != 0; --i) {
             rec_wait(A);
             rec_request(stream_rec, off + 64u, B);
-            l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor), touch_off, sink);
+            l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor) - touch_back, touch_off, sink);
             blend(A);
             rec_wait(B);
             rec_request(stream_rec, min(off + 128u, off_last), A);   // (the last record again after the last pair)
@@ -229,8 +248,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
             off += 128u;
         }
         rec_wait(A);
+        l2_touch_drain(sink);   // before any other code: once the loop is left the compiler may reuse the sink's register
         if (n & 1u) blend(A);
-        l2_touch_drain(sink);
     }
     if (!w.vx) return;
 #pragma unroll
@@ -337,8 +356,8 @@ template <int MODE>
 __device__ inline void put_record(float *pairgrad, uint32_t rec_off, uint32_t lane_off, float val,
                                   unsigned long long writers, const GroupSlot &gs)
 {
-    const uint32_t voff = lane_off + rec_off;
     if (MODE == kAtomic) {
+        const uint32_t voff = lane_off + rec_off;
         // several waves share the record; it was zeroed by the launcher
         if (((writers >> (threadIdx.x & 63)) & 1ull) && val != 0.0f)
             atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(pairgrad) + voff), val);
@@ -348,12 +367,14 @@ __device__ inline void put_record(float *pairgrad, uint32_t rec_off, uint32_t la
             gs.parts[(e * kGroupMaxWaves + gs.block) * GSR_PAIRGRAD_FLOATS + (lane_off >> 2)] = val;
         if (gs.block == 0 && (threadIdx.x & 63) == 0) gs.slots[e] = rec_off / (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));
     } else {
-        // every lane of the wave is active here: set the writers, store, restore
-        asm volatile("s_mov_b64 exec, %3\n\t"
+        // every lane of the wave is active here: set the writers, store, restore.  The record's address is
+        // wave-uniform and added on the scalar unit; the lane's offset inside a record never changes.
+        const char *record = uniform_address(reinterpret_cast<const char *>(pairgrad) + rec_off);
+        asm volatile(kSgprReady "s_mov_b64 exec, %3\n\t"
                      "global_store_dword %0, %1, %2\n\t"
                      "s_mov_b64 exec, -1"
                      :
-                     : "v"(voff), "v"(val), "s"(pairgrad), "s"(writers)
+                     : "v"(lane_off), "v"(val), "s"(record), "s"(writers)
                      : "memory");
     }
 }
@@ -392,11 +413,11 @@ __device__ inline float reduce_full(const RecordLanes &L, float vx, float vy, fl
 
 // Colour-only record (the clamp blocks every other gradient of the entry).
 template <int MODE>
-__device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad, uint32_t rec_off, const GroupSlot &gs, float unscale, float r,
+__device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad, uint32_t rec_off, const GroupSlot &gs, float r,
                                            float g, float b)
 {
     const float rows = sum16(merge_rows(merge_halves(r, g), b));   // rows: red, blue(0-1), green, blue(2-3)
-    put_record<MODE>(pairgrad, rec_off, L.col_off, L.col_zero ? 0.0f : rows * unscale, kColWriters, gs);
+    put_record<MODE>(pairgrad, rec_off, L.col_off, L.col_zero ? 0.0f : rows, kColWriters, gs);
 }
 
 // Reverse sweep of one list for the 4 pixels of a lane.  CHECK: pixel j only takes part in
@@ -404,7 +425,7 @@ __device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad
 template <bool CHECK, int MODE>
 __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ stream_rec, const float pxf,
                                  const f2 (&pyf)[2], f2 (&T)[2], const f2 (&gr)[2], const f2 (&gg)[2],
-                                 const f2 (&gb)[2], const uint32_t (&nstop)[4], const float unscale,
+                                 const f2 (&gb)[2], const uint32_t (&nstop)[4],
                                  float *__restrict__ pairgrad, GroupSlot gs)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
@@ -418,7 +439,6 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     // record's layout: red, green, four partial sums of blue over the rows of lanes) and follows from the sums
     // every other entry reduces anyway.
     const float low_gain = lanes.colour * (kAlphaMin / (1.0f - kAlphaMin));
-    const float low_gain_out = low_gain * unscale;
     float U = 0.0f;
     if (!CHECK) {
         const f2 ur = pk_fma(T[1], gr[1], T[0] * gr[0]), ug = pk_fma(T[1], gg[1], T[0] * gg[0]), ub = pk_fma(T[1], gb[1], T[0] * gb[0]);
@@ -516,11 +536,11 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             if (CHECK) {
                 half_low(0, R, k, red, true, true);
                 half_low(1, R, k, red, false, true);
-                reduce_store_colour<MODE>(lanes, pairgrad, rec_off, gs, unscale, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+                reduce_store_colour<MODE>(lanes, pairgrad, rec_off, gs, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
             } else {
                 half_low(0, R, k, red, true, false);
                 half_low(1, R, k, red, false, false);
-                put_record<MODE>(pairgrad, rec_off, lanes.full_off, U * low_gain_out, kFullWriters, gs);   // zeros in floats 0..5
+                put_record<MODE>(pairgrad, rec_off, lanes.full_off, U * low_gain, kFullWriters, gs);   // zeros in floats 0..5
                 U = fmaf(U, low_gain, U);
             }
             return;
@@ -541,7 +561,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         const float val = reduce_full(lanes, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y, s_yy.x + s_yy.y, s_o.x + s_o.y,
                                       s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
         if (!CHECK) U = fmaf(val, lanes.colour, U);
-        put_record<MODE>(pairgrad, rec_off, lanes.full_off, val * unscale, kFullWriters, gs);
+        put_record<MODE>(pairgrad, rec_off, lanes.full_off, val, kFullWriters, gs);
     };
     // back to front, two record buffers alternating (see composite_fwd_kernel); k is only needed by
     // the checked variant
@@ -571,11 +591,11 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         if (CHECK) k -= 2u;
     }
     rec_wait(A);
+    l2_touch_drain(sink);   // (before the odd entry: see composite_fwd_kernel)
     if (n & 1u) {
         entry(A, k);
         if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
     }
-    l2_touch_drain(sink);
     // (every wave of a tile group walks the same list: the barriers inside the flushes match up)
     if (MODE == kTileGroup && gs.entry != 0) group_flush(gs, gs.entry, pairgrad);
 }
@@ -660,7 +680,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // loop that waits for every record before it asks for the next one runs at the latency of L2
             const uint32_t off_last = (w.end - 1) * 64u, off_stream_last = (w.total - 1) * 64u;
             const uint32_t touch_floor = min(64u, off_stream_last);
-            const uint32_t touch_off = ((threadIdx.x & 1) && w.total > 1u) ? 0u - 64u : 0u;
+            const uint32_t touch_back = w.total > 1u ? 64u : 0u;
+            const uint32_t touch_off = (threadIdx.x & 1) ? 0u : touch_back;
             uint32_t off = w.begin * 64u, idx = 0u;
             float sink = 0.0f;
             Rec A, B;
@@ -668,7 +689,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (uint32_t i = len >> 1; i != 0; --i) {
                 rec_wait(A);
                 rec_request(stream_rec, off + 64u, B);
-                l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor), touch_off, sink);
+                l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor) - touch_back, touch_off, sink);
                 forward_step(A, idx);
                 rec_wait(B);
                 rec_request(stream_rec, min(off + 128u, off_last), A);   // (the last record again after the last pair)
@@ -677,26 +698,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 idx += 2u;
             }
             rec_wait(A);
-            if (len & 1u) forward_step(A, idx);
             l2_touch_drain(sink);
+            if (len & 1u) forward_step(A, idx);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool inside = w.vx && (w.y0 + 4 * j) < w.ylim;
             if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
-        bwd_sweep<true, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, 1.0f, pairgrad, gs);
+        bwd_sweep<true, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, gs);
     } else {
         // Between kTinyT and the smallest normal number the plain sweep still works on a transmittance
-        // scaled by a power of two (exact): everything the sweep accumulates is linear in T, so the sums
-        // of the wave come out scaled by the same factor and are scaled back when a record is stored.
-        float unscale = 1.0f;
+        // scaled up by a power of two (exact).  Everything the sweep accumulates is a product of one
+        // transmittance and one cotangent, so the wave scales its cotangents down by the same factor and
+        // its sums come out unscaled.
         if (__ballot(small) != 0ull) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) T[h] = T[h] * splat(kRescue);
-            unscale = 1.0f / kRescue;
+            for (int h = 0; h < 2; ++h) {
+                T[h] = T[h] * splat(kRescue);
+                gr[h] = gr[h] * splat(1.0f / kRescue); gg[h] = gg[h] * splat(1.0f / kRescue); gb[h] = gb[h] * splat(1.0f / kRescue);
+            }
         }
-        bwd_sweep<false, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, unscale, pairgrad, gs);
+        bwd_sweep<false, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, gs);
     }
 }
 
