@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t f = q * 64 + lane;
-        if (f < wave_f4) dst[f] = wave_tile[f];
+        if (f < wave_f4) { typedef float v4f __attribute__((ext_vector_type(4))); const float4 t4 = wave_tile[f]; __builtin_nontemporal_store(v4f{t4.x, t4.y, t4.z, t4.w}, reinterpret_cast<v4f *>(&dst[f])); }
     }
 }
 
