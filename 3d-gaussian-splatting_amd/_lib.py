@@ -20,11 +20,13 @@ ADAM_MAX_TENSORS = 8
 
 # Every symbol include/gsr.h declares.
 SYMBOLS = (
-    "gsr_last_error", "gsr_version", "gsr_preprocess_fwd", "gsr_preprocess_bwd", "gsr_preprocess_bwd_workspace_bytes",
+    "gsr_last_error", "gsr_version", "gsr_preprocess_fwd", "gsr_preprocess_fwd_views", "gsr_preprocess_bwd",
+    "gsr_preprocess_bwd_workspace_bytes",
     "gsr_pair_reduce", "gsr_preprocess_bwd_views", "gsr_sh_grad_views",
     "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_sort_pairs64", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
     "gsr_exclusive_scan_static",
-    "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order",
+    "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_offsets_views_workspace_bytes", "gsr_bin_offsets_views",
+    "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order",
     "gsr_composite_fwd", "gsr_composite_bwd", "gsr_pairgrad_parts",
     "gsr_loss_workspace_bytes", "gsr_loss_fwd_bwd",
     "gsr_adam_step", "gsr_knn_dist2",
@@ -86,6 +88,7 @@ def load():
         getattr(lib, name).argtypes = [C.c_uint32]
     vp = C.c_void_p
     lib.gsr_preprocess_fwd.argtypes = [C.POINTER(GsrView)] + [vp] * 16
+    lib.gsr_preprocess_fwd_views.argtypes = [C.POINTER(GsrView), C.c_uint32] + [vp] * 15
     lib.gsr_preprocess_bwd.argtypes = [C.POINTER(GsrView)] + [vp] * 15 + [C.c_int, vp, C.c_size_t, vp]
     lib.gsr_pair_reduce.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.gsr_pairgrad_parts.restype = C.c_uint32
@@ -98,6 +101,9 @@ def load():
     lib.gsr_exclusive_scan.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_size_t, vp]
     lib.gsr_exclusive_scan_static.argtypes = [vp, vp, C.c_uint32, vp, vp]
     lib.gsr_bin_offsets.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_bin_offsets_views_workspace_bytes.restype = C.c_size_t
+    lib.gsr_bin_offsets_views_workspace_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    lib.gsr_bin_offsets_views.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_bin_lists.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_tile_order.argtypes = [C.POINTER(GsrView), vp, vp, vp]
     lib.gsr_composite_fwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, vp]

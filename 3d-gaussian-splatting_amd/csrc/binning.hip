@@ -10,10 +10,11 @@
 
 namespace {
 
+// (blockIdx.y: one of several sequences of n that lie one after the other)
 __global__ void iota_kernel(uint32_t *__restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = i;
+    if (i < n) out[(size_t)blockIdx.y * n + i] = i;
 }
 
 // Emits (tile id, owner | slot) for every slot.  Slot e of Gaussian g: e = slot_base[g] + (xi - x0) * ny
@@ -304,6 +305,53 @@ extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint
                                          slot_seq, &counters->error))
         return e;
     return gsr_check_launch("bin_offsets");
+}
+
+extern "C" size_t gsr_bin_offsets_views_workspace_bytes(uint32_t n, uint32_t num_views)
+{
+    const size_t arr = align256((size_t)(n ? n : 1) * (num_views ? num_views : 1) * sizeof(uint32_t));
+    return 2 * arr + (size_t)(num_views ? num_views : 1) * (gsr_sort_workspace_bytes(n) + gsr_scan_workspace_bytes(n));
+}
+
+extern "C" int gsr_bin_offsets_views(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uint32_t num_views,
+                                     uint32_t *order, uint32_t *slot_base, uint32_t *slot_seq, gsr_counters *counters,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (num_views == 0) return GSR_OK;
+    if (!workspace || workspace_bytes < gsr_bin_offsets_views_workspace_bytes(n, num_views)) {
+        gsr_set_error("gsr_bin_offsets_views: workspace too small");
+        return GSR_ERR_ARG;
+    }
+    if (!counters) { gsr_set_error("gsr_bin_offsets_views: null counters"); return GSR_ERR_ARG; }
+    if ((unsigned long long)n * num_views >= (1ull << 32)) { gsr_set_error("gsr_bin_offsets_views: too many keys"); return GSR_ERR_ARG; }
+    if (n == 0) {
+        for (uint32_t k = 0; k < num_views; ++k) {
+            (void)hipMemsetAsync(&counters[k].num_pairs, 0, sizeof(uint32_t), st);
+            if (slot_seq) (void)hipMemsetAsync(slot_seq + k, 0, sizeof(uint32_t), st);
+        }
+        return GSR_OK;
+    }
+    if (!depth_key || !ntiles || !order || !slot_base) { gsr_set_error("gsr_bin_offsets_views: null pointer"); return GSR_ERR_ARG; }
+    const size_t arr = align256((size_t)n * num_views * sizeof(uint32_t));
+    char *ws = (char *)workspace;
+    uint32_t *ids_b = (uint32_t *)ws;             // second value buffer of the sort
+    uint32_t *keys_b = (uint32_t *)(ws + arr);    // second key buffer of the sort
+    void *sort_ws = ws + 2 * arr;
+    const size_t sort_bytes = (size_t)num_views * gsr_sort_workspace_bytes(n);
+    void *scan_ws = (char *)sort_ws + sort_bytes;
+    const size_t scan_bytes = (size_t)num_views * gsr_scan_workspace_bytes(n);
+    hipLaunchKernelGGL(iota_kernel, dim3(gsr_div_up(n, 256), num_views), dim3(256), 0, st, order, n);
+    bool in_first;
+    if (int e = gsr_sort_pingpong32_batch(depth_key, order, keys_b, ids_b, n, num_views, 0, 32, sort_ws, sort_bytes, stream,
+                                          &in_first))
+        return e;
+    if (!in_first) { gsr_set_error("gsr_bin_offsets_views: unexpected number of sort passes"); return GSR_ERR_LAUNCH; }
+    if (int e = gsr_exclusive_scan_along_batch(ntiles, order, slot_base, n, num_views, &counters->num_pairs, &counters->error,
+                                               (uint32_t)(sizeof(gsr_counters) / sizeof(uint32_t)), scan_ws, scan_bytes, stream,
+                                               slot_seq))
+        return e;
+    return gsr_check_launch("bin_offsets_views");
 }
 
 extern "C" size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs)

@@ -27,6 +27,12 @@ int gsr_sort_pingpong32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, ui
                         int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
 int gsr_sort_pingpong64(uint32_t *keys_a, uint64_t *vals_a, uint32_t *keys_b, uint64_t *vals_b, uint32_t n, int begin_bit,
                         int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
+int gsr_sort_pingpong32_batch(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, uint32_t nseq,
+                              int begin_bit, int end_bit, void *workspace, size_t workspace_bytes, void *stream,
+                              bool *result_in_first);   // nseq sequences of n pairs, one after the other
+int gsr_exclusive_scan_along_batch(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t nseq,
+                                   uint32_t *total, uint32_t *overflow_flag, uint32_t counter_stride, void *workspace,
+                                   size_t workspace_bytes, void *stream, uint32_t *out_seq);
 int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
                              void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq,
                              uint32_t *overflow_flag /* bit 1 raised when the total does not fit 32 bits; may be null */);

@@ -209,13 +209,115 @@ __device__ inline void load_sh(const float *sh, int i, int K, float co[3][16])
         }
 }
 
+// Where stage 1 leaves what it computes for one view (every array is indexed by Gaussian).
+struct FwdOut {
+    uint8_t *mask;
+    uint32_t *depth_key;
+    float *pos2d, *cov2d, *radius;
+    int32_t *bbox;
+    uint32_t *ntiles;
+    float *rec;
+};
+
+// Gaussian i in view v, from the view-independent part in g (geometry_model): projection and cull, 2-D
+// covariance, radius, integer bounding box, tile count, colour, splat record.  `co`: the Gaussian's sh
+// coefficients, loaded on the first view that sees it (`co_loaded`).  Returns whether the Gaussian is visible.
+__device__ inline bool project_to_view(const ViewK &v, int i, const float p[3], Geom &g, const float *__restrict__ opac_raw,
+                                       const float *__restrict__ sh, const float *__restrict__ screen_coords, float (&co)[3][16],
+                                       bool &co_loaded, const FwdOut &out, bool &singular)
+{
+    geometry_view(v.w2m, v.proj, p, g);
+    // Utils/Camera.py:106-108 (NaN compares false: culled)
+    const bool vis = (g.ndc[2] >= 0.1f) && (-1.3f <= g.ndc[0]) && (g.ndc[0] <= 1.3f) && (-1.3f <= g.ndc[1]) &&
+                     (g.ndc[1] <= 1.3f);
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    float px = 0.f, py = 0.f, pz = 0.f, rad = 0.f;
+    float cv[4] = {0.f, 0.f, 0.f, 0.f};
+    int bx[4] = {0, 0, 0, 0};
+    uint32_t nt = 0, key = 0xFFFFFFFFu;
+    if (vis) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        if (screen_coords) { sx = screen_coords[3 * i]; sy = screen_coords[3 * i + 1]; sz = screen_coords[3 * i + 2]; }
+        // Utils/Camera.py:111-115
+        px = sx + g.ndc[0]; py = sy + g.ndc[1]; pz = sz + g.ndc[2];
+        px = (0.5f * (px + 1.0f)) * v.Wf;
+        py = (1.0f - 0.5f * (py + 1.0f)) * v.Hf;
+        key = __float_as_uint(pz);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cv[k] = g.cov2[k];
+        // GaussianRenderer.py:40-44
+        const float a = cv[0], b = cv[1], c = cv[2], d = cv[3];
+        const float trace = a + d;
+        const float det = a * d - b * c;
+        const float term1 = 0.5f * trace;
+        float disc = trace * trace - 4.0f * det;
+        if (disc < 0.0f) disc = 0.0f;
+        const float term2 = 0.5f * sqrtf(disc);
+        const float lo = term1 - term2, hi = term1 + term2;
+        rad = 3.0f * sqrtf(lo > hi ? lo : hi);
+        // Utils/Screen.py:33-36: clamp, then truncate; a NaN edge gives an empty box
+        const float e[4] = {px - rad, py - rad, px + rad, py + rad};
+        const float lim[4] = {v.Wf, v.Hf, v.Wf, v.Hf};
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = e[k];
+            if (t != t) { bad = true; t = 0.0f; }
+            if (t < 0.0f) t = 0.0f;
+            if (t > lim[k]) t = lim[k];
+            bx[k] = (int)t;
+        }
+        if (bad) bx[0] = bx[1] = bx[2] = bx[3] = 0;
+        int x0, x1, y0, y1;
+        gsr_tile_span(bx[0], bx[2], v.L, x0, x1);
+        gsr_tile_span(bx[1], bx[3], v.L, y0, y1);
+        nt = (uint32_t)(x1 - x0 + 1) * (uint32_t)(y1 - y0 + 1);
+        singular = singular || (nt > 0 && lu2_singular(cv));
+        // inverse 2x2, pre-scaled so that G = exp2(A' dx^2 + B' dx dy + D' dy^2)
+        const float idet = 1.0f / det;
+        const float kk = -0.5f * 1.4426950408889634f;
+        const float ia = d * idet, ib = -b * idet, ic = -c * idet, id = a * idet;
+        // GaussianModel.py:58-60
+        const float o = 1.0f / (1.0f + expf(-opac_raw[i]));
+        // GaussianRenderer.py:71-74
+        float bs[16];
+        if (!co_loaded) { load_sh(sh, i, v.K, co); co_loaded = true; }
+        sh_basis(v.deg, p[0] - v.cam[0], p[1] - v.cam[1], p[2] - v.cam[2], bs);
+        float col[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < v.K) acc += bs[k] * co[ch][k];
+            acc += 0.5f;
+            col[ch] = acc < 0.0f ? 0.0f : acc;
+        }
+        // A NaN opacity makes alpha NaN in the reference (torch.clamp keeps NaN, GaussianRenderer.py:104)
+        // and with it every pixel of the Gaussian's tiles.  The compositing kernels clamp with min/max
+        // instructions, which drop a NaN operand, so the NaN is handed on through the colour instead:
+        // the image comes out NaN in the same pixels and a diverged model stays visible in the loss.
+        if (o != o) col[0] = col[1] = col[2] = o;
+        r0 = make_float4(px, py, kk * ia, kk * (ib + ic));
+        r1 = make_float4(kk * id, o, col[0], col[1]);
+        r2 = make_float4(col[2], ia, 0.5f * (ib + ic), id);
+    }
+    out.mask[i] = vis ? 1 : 0;
+    out.depth_key[i] = key;
+    out.pos2d[3 * i] = px; out.pos2d[3 * i + 1] = py; out.pos2d[3 * i + 2] = pz;
+    reinterpret_cast<float4 *>(out.cov2d)[i] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+    out.radius[i] = rad;
+    reinterpret_cast<int4 *>(out.bbox)[i] = make_int4(bx[0], bx[1], bx[2], bx[3]);
+    out.ntiles[i] = nt;
+    float4 *dst = reinterpret_cast<float4 *>(out.rec + (size_t)i * GSR_REC_FLOATS);
+    dst[0] = r0; dst[1] = r1; dst[2] = r2;
+    return vis;
+}
+
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     ViewK v, const float *__restrict__ coords, const float *__restrict__ scale_raw,
     const float *__restrict__ rot_raw, const float *__restrict__ opac_raw, const float *__restrict__ sh,
-    const float *__restrict__ screen_coords, uint8_t *__restrict__ mask, uint32_t *__restrict__ depth_key,
-    float *__restrict__ pos2d, float *__restrict__ cov2d, float *__restrict__ radius,
-    int32_t *__restrict__ bbox, uint32_t *__restrict__ ntiles, float *__restrict__ rec,
-    gsr_counters *__restrict__ counters)
+    const float *__restrict__ screen_coords, FwdOut out, gsr_counters *__restrict__ counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool vis = false;
@@ -226,91 +328,10 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         const float4 q4 = reinterpret_cast<const float4 *>(rot_raw)[i];
         const float qr[4] = {q4.x, q4.y, q4.z, q4.w};
         Geom g;
-        geometry(v, p, sr, qr, g);
-        // Utils/Camera.py:106-108 (NaN compares false: culled)
-        vis = (g.ndc[2] >= 0.1f) && (-1.3f <= g.ndc[0]) && (g.ndc[0] <= 1.3f) && (-1.3f <= g.ndc[1]) &&
-              (g.ndc[1] <= 1.3f);
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-        float px = 0.f, py = 0.f, pz = 0.f, rad = 0.f;
-        float cv[4] = {0.f, 0.f, 0.f, 0.f};
-        int bx[4] = {0, 0, 0, 0};
-        uint32_t nt = 0, key = 0xFFFFFFFFu;
-        if (vis) {
-            float sx = 0.f, sy = 0.f, sz = 0.f;
-            if (screen_coords) { sx = screen_coords[3 * i]; sy = screen_coords[3 * i + 1]; sz = screen_coords[3 * i + 2]; }
-            // Utils/Camera.py:111-115
-            px = sx + g.ndc[0]; py = sy + g.ndc[1]; pz = sz + g.ndc[2];
-            px = (0.5f * (px + 1.0f)) * v.Wf;
-            py = (1.0f - 0.5f * (py + 1.0f)) * v.Hf;
-            key = __float_as_uint(pz);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cv[k] = g.cov2[k];
-            // GaussianRenderer.py:40-44
-            const float a = cv[0], b = cv[1], c = cv[2], d = cv[3];
-            const float trace = a + d;
-            const float det = a * d - b * c;
-            const float term1 = 0.5f * trace;
-            float disc = trace * trace - 4.0f * det;
-            if (disc < 0.0f) disc = 0.0f;
-            const float term2 = 0.5f * sqrtf(disc);
-            const float lo = term1 - term2, hi = term1 + term2;
-            rad = 3.0f * sqrtf(lo > hi ? lo : hi);
-            // Utils/Screen.py:33-36: clamp, then truncate; a NaN edge gives an empty box
-            const float e[4] = {px - rad, py - rad, px + rad, py + rad};
-            const float lim[4] = {v.Wf, v.Hf, v.Wf, v.Hf};
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float t = e[k];
-                if (t != t) { bad = true; t = 0.0f; }
-                if (t < 0.0f) t = 0.0f;
-                if (t > lim[k]) t = lim[k];
-                bx[k] = (int)t;
-            }
-            if (bad) bx[0] = bx[1] = bx[2] = bx[3] = 0;
-            int x0, x1, y0, y1;
-            gsr_tile_span(bx[0], bx[2], v.L, x0, x1);
-            gsr_tile_span(bx[1], bx[3], v.L, y0, y1);
-            nt = (uint32_t)(x1 - x0 + 1) * (uint32_t)(y1 - y0 + 1);
-            singular = nt > 0 && lu2_singular(cv);
-            // inverse 2x2, pre-scaled so that G = exp2(A' dx^2 + B' dx dy + D' dy^2)
-            const float idet = 1.0f / det;
-            const float kk = -0.5f * 1.4426950408889634f;
-            const float ia = d * idet, ib = -b * idet, ic = -c * idet, id = a * idet;
-            // GaussianModel.py:58-60
-            const float o = 1.0f / (1.0f + expf(-opac_raw[i]));
-            // GaussianRenderer.py:71-74
-            float co[3][16], bs[16];
-            load_sh(sh, i, v.K, co);
-            sh_basis(v.deg, p[0] - v.cam[0], p[1] - v.cam[1], p[2] - v.cam[2], bs);
-            float col[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < v.K) acc += bs[k] * co[ch][k];
-                acc += 0.5f;
-                col[ch] = acc < 0.0f ? 0.0f : acc;
-            }
-            // A NaN opacity makes alpha NaN in the reference (torch.clamp keeps NaN, GaussianRenderer.py:104)
-            // and with it every pixel of the Gaussian's tiles.  The compositing kernels clamp with min/max
-            // instructions, which drop a NaN operand, so the NaN is handed on through the colour instead:
-            // the image comes out NaN in the same pixels and a diverged model stays visible in the loss.
-            if (o != o) col[0] = col[1] = col[2] = o;
-            r0 = make_float4(px, py, kk * ia, kk * (ib + ic));
-            r1 = make_float4(kk * id, o, col[0], col[1]);
-            r2 = make_float4(col[2], ia, 0.5f * (ib + ic), id);
-        }
-        mask[i] = vis ? 1 : 0;
-        depth_key[i] = key;
-        pos2d[3 * i] = px; pos2d[3 * i + 1] = py; pos2d[3 * i + 2] = pz;
-        reinterpret_cast<float4 *>(cov2d)[i] = make_float4(cv[0], cv[1], cv[2], cv[3]);
-        radius[i] = rad;
-        reinterpret_cast<int4 *>(bbox)[i] = make_int4(bx[0], bx[1], bx[2], bx[3]);
-        ntiles[i] = nt;
-        float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)i * GSR_REC_FLOATS);
-        dst[0] = r0; dst[1] = r1; dst[2] = r2;
+        geometry_model(sr, qr, g);
+        float co[3][16];
+        bool co_loaded = false;
+        vis = project_to_view(v, i, p, g, opac_raw, sh, screen_coords, co, co_loaded, out, singular);
     }
     // One atomic per BLOCK for the visible count: atomics of all waves on one address serialise at
     // about 7 ns each, which at one per wave (15.6 k waves for a million Gaussians) costs more than the
@@ -324,6 +345,52 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         if (c) atomicAdd(&counters->num_visible, c);
     }
     if (singular) atomicOr(&counters->error, 1u);
+}
+
+// Stage 1 of several views of the same Gaussians in one pass: the parameters are read once (236 bytes per
+// Gaussian, most of what the one-view kernel moves) and the view-independent part - activations, rotation,
+// 3-D covariance - is computed once.  The outputs of view k start k * n elements (rows) into each array.
+constexpr int kMaxFwdViews = 8;
+struct FwdViews {
+    ViewK v[kMaxFwdViews];
+    int nv;
+};
+
+__global__ __launch_bounds__(256) void preprocess_fwd_views_kernel(
+    FwdViews views, const float *__restrict__ coords, const float *__restrict__ scale_raw,
+    const float *__restrict__ rot_raw, const float *__restrict__ opac_raw, const float *__restrict__ sh, FwdOut out0,
+    gsr_counters *__restrict__ counters)
+{
+    const int n = views.v[0].n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t visible[kMaxFwdViews];
+    if (threadIdx.x < kMaxFwdViews) visible[threadIdx.x] = 0;
+    __syncthreads();
+    float p[3] = {0.f, 0.f, 0.f};
+    Geom g;
+    float co[3][16];
+    bool co_loaded = false;
+    if (i < n) {
+        p[0] = coords[3 * i]; p[1] = coords[3 * i + 1]; p[2] = coords[3 * i + 2];
+        const float sr[3] = {scale_raw[3 * i], scale_raw[3 * i + 1], scale_raw[3 * i + 2]};
+        const float4 q4 = reinterpret_cast<const float4 *>(rot_raw)[i];
+        const float qr[4] = {q4.x, q4.y, q4.z, q4.w};
+        geometry_model(sr, qr, g);
+    }
+    for (int k = 0; k < views.nv; ++k) {
+        bool vis = false, singular = false;
+        if (i < n) {
+            const size_t at = (size_t)k * (size_t)n;
+            const FwdOut out = {out0.mask + at, out0.depth_key + at, out0.pos2d + 3 * at, out0.cov2d + 4 * at, out0.radius + at,
+                                out0.bbox + 4 * at, out0.ntiles + at, out0.rec + GSR_REC_FLOATS * at};
+            vis = project_to_view(views.v[k], i, p, g, opac_raw, sh, nullptr, co, co_loaded, out, singular);
+        }
+        const unsigned long long bal = __ballot(vis);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&visible[k], (uint32_t)__popcll(bal));
+        if (singular) atomicOr(&counters[k].error, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < views.nv && visible[threadIdx.x]) atomicAdd(&counters[threadIdx.x].num_visible, visible[threadIdx.x]);
 }
 
 template <bool ACC>
@@ -762,10 +829,42 @@ extern "C" int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords
         return GSR_ERR_ARG;
     }
     if (v.n == 0) return GSR_OK;
+    const FwdOut out = {mask, depth_key, pos2d, cov2d, radius, bbox, ntiles, rec};
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, (hipStream_t)stream, v,
-                       coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, mask, depth_key, pos2d, cov2d,
-                       radius, bbox, ntiles, rec, counters);
+                       coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, out, counters);
     return gsr_check_launch("preprocess_fwd");
+}
+
+extern "C" int gsr_preprocess_fwd_views(const gsr_view *views_host, uint32_t num_views, const float *coords,
+                                        const float *scale_raw, const float *rot_raw, const float *opac_raw, const float *sh,
+                                        uint8_t *mask, uint32_t *depth_key, float *pos2d, float *cov2d, float *radius,
+                                        int32_t *bbox, uint32_t *ntiles, float *rec, gsr_counters *counters, void *stream)
+{
+    if (!views_host || num_views == 0 || num_views > (uint32_t)kMaxFwdViews) {
+        gsr_set_error("gsr_preprocess_fwd_views: %u views (1..%d expected)", num_views, kMaxFwdViews);
+        return GSR_ERR_ARG;
+    }
+    FwdViews views;
+    views.nv = (int)num_views;
+    for (uint32_t k = 0; k < num_views; ++k) {
+        if (int e = gsr_make_view(&views_host[k], &views.v[k])) return e;
+        if (views.v[k].n != views.v[0].n || views.v[k].deg != views.v[0].deg) {
+            gsr_set_error("gsr_preprocess_fwd_views: view %u differs from view 0 in the number of Gaussians or the sh degree", k);
+            return GSR_ERR_ARG;
+        }
+    }
+    for (uint32_t k = num_views; k < (uint32_t)kMaxFwdViews; ++k) views.v[k] = views.v[0];
+    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !mask || !depth_key || !pos2d || !cov2d ||
+        !radius || !bbox || !ntiles || !rec || !counters) {
+        gsr_set_error("gsr_preprocess_fwd_views: null pointer");
+        return GSR_ERR_ARG;
+    }
+    const int n = views.v[0].n;
+    if (n == 0) return GSR_OK;
+    const FwdOut out = {mask, depth_key, pos2d, cov2d, radius, bbox, ntiles, rec};
+    hipLaunchKernelGGL(preprocess_fwd_views_kernel, dim3(gsr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, views,
+                       coords, scale_raw, rot_raw, opac_raw, sh, out, counters);
+    return gsr_check_launch("preprocess_fwd_views");
 }
 
 extern "C" size_t gsr_preprocess_bwd_workspace_bytes(uint32_t n)

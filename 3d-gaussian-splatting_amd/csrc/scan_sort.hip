@@ -49,15 +49,27 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t x, uint32_t *lds, uint3
     return base + inc - x;
 }
 
+// Several independent sequences of the same length can be processed by one launch: sequence y = blockIdx.y
+// starts y * n elements into in / idx / out (y * (n + 1) into out_seq, y * nb into block_sums) and owns the
+// y-th `Counters` record (total, overflow flag).
+struct SegCounters {
+    uint32_t *total;           // may be null
+    uint32_t *overflow_flag;   // may be null
+    uint32_t stride;           // words between the records of two sequences
+};
+
 // With idx != null element i of the sequence is in[idx[i]] and its result goes to out[idx[i]]
 // (a scan along a permutation; in and out may then not alias).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t *__restrict__ in,
                                                                    const uint32_t *__restrict__ idx, uint32_t n,
-                                                                   uint32_t *__restrict__ block_sums,
-                                                                   uint32_t *__restrict__ overflow_flag)
+                                                                   uint32_t *__restrict__ block_sums, SegCounters cnt)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
     __shared__ unsigned long long wide;
+    in += (size_t)blockIdx.y * n;
+    if (idx) idx += (size_t)blockIdx.y * n;
+    block_sums += (size_t)blockIdx.y * gridDim.x;
+    uint32_t *overflow_flag = cnt.overflow_flag ? cnt.overflow_flag + (size_t)blockIdx.y * cnt.stride : nullptr;
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
     unsigned long long s64 = 0;
@@ -84,12 +96,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 }
 
 // One block: exclusive scan of block_sums[0..nb) in place, total to *total_out (may be null).
-__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ block_sums, uint32_t nb,
-                                                         uint32_t *__restrict__ total_out,
-                                                         uint32_t *__restrict__ overflow_flag)
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ block_sums, uint32_t nb, SegCounters cnt)
 {
     __shared__ uint32_t lds[1024 / 64 + 1];
     __shared__ unsigned long long wide;
+    block_sums += (size_t)blockIdx.y * nb;
+    uint32_t *total_out = cnt.total ? cnt.total + (size_t)blockIdx.y * cnt.stride : nullptr;
+    uint32_t *overflow_flag = cnt.overflow_flag ? cnt.overflow_flag + (size_t)blockIdx.y * cnt.stride : nullptr;
     if (threadIdx.x == 0) wide = 0ull;
     uint32_t carry = 0;
     unsigned long long mine = 0;
@@ -122,6 +135,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
                                                                   uint32_t *__restrict__ out_seq)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+    in += (size_t)blockIdx.y * n;
+    out += (size_t)blockIdx.y * n;
+    if (idx) idx += (size_t)blockIdx.y * n;
+    if (out_seq) out_seq += (size_t)blockIdx.y * (n + 1);
+    block_sums += (size_t)blockIdx.y * gridDim.x;
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS], at[SCAN_ITEMS];
     uint32_t s = 0;
@@ -156,6 +174,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     __shared__ uint32_t h[RADIX_SIZE];
     h[threadIdx.x] = 0;
     __syncthreads();
+    // (sequence blockIdx.y of a batch of equally long ones: y * n keys and y * 256 * nb counts further on)
+    keys += (size_t)blockIdx.y * n;
+    hist += (size_t)blockIdx.y * RADIX_SIZE * nb;
     const uint32_t base = blockIdx.x * SORT_TILE;
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
@@ -173,6 +194,8 @@ __global__ __launch_bounds__(256) void radix_rows_kernel(uint32_t *__restrict__ 
                                                          uint32_t *__restrict__ digit_total)
 {
     __shared__ uint32_t lds[256 / 64 + 1];
+    hist += (size_t)blockIdx.y * RADIX_SIZE * nb;
+    digit_total += (size_t)blockIdx.y * RADIX_SIZE;
     uint32_t *row = hist + (size_t)blockIdx.x * nb;
     uint32_t carry = 0;
     for (uint32_t start = 0; start < nb; start += 256) {
@@ -207,6 +230,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     __shared__ V stage[STAGED ? SORT_TILE : 1];        // keys (as words), then values, in digit order
     uint32_t *stage_keys = reinterpret_cast<uint32_t *>(stage);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    keys_in += (size_t)blockIdx.y * n; vals_in += (size_t)blockIdx.y * n;
+    keys_out += (size_t)blockIdx.y * n; vals_out += (size_t)blockIdx.y * n;
+    hist_rows += (size_t)blockIdx.y * RADIX_SIZE * nb;
+    digit_total += (size_t)blockIdx.y * RADIX_SIZE;
     // first position of digit d in the output: exclusive scan of the 256 digit totals
     uint32_t digit_base;
     {
@@ -322,29 +349,43 @@ extern "C" size_t gsr_scan_workspace_bytes(uint32_t n)
     return align256((size_t)gsr_div_up(n ? n : 1, SCAN_TILE) * sizeof(uint32_t));
 }
 
-// library-internal: out[idx[i]] = sum over j < i of in[idx[j]]  (idx == null: the plain scan)
-int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
-                             void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq,
-                             uint32_t *overflow_flag)
+// library-internal: out[idx[i]] = sum over j < i of in[idx[j]]  (idx == null: the plain scan), for `nseq`
+// independent sequences of n elements each that lie one after the other in every array (out_seq: n + 1 per
+// sequence); total and overflow_flag point at the first sequence's words, `counter_stride` words apart from
+// the next one's.  The workspace holds nseq times gsr_scan_workspace_bytes(n).
+int gsr_exclusive_scan_along_batch(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t nseq,
+                                   uint32_t *total, uint32_t *overflow_flag, uint32_t counter_stride, void *workspace,
+                                   size_t workspace_bytes, void *stream, uint32_t *out_seq)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (workspace_bytes < gsr_scan_workspace_bytes(n) || !workspace) {
+    if (nseq == 0) return GSR_OK;
+    if (workspace_bytes < nseq * gsr_scan_workspace_bytes(n) || !workspace) {
         gsr_set_error("gsr_exclusive_scan: workspace too small (%zu < %zu)", workspace_bytes,
-                      gsr_scan_workspace_bytes(n));
+                      nseq * gsr_scan_workspace_bytes(n));
         return GSR_ERR_ARG;
     }
     if (n == 0) {
-        if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), st);
-        if (out_seq) (void)hipMemsetAsync(out_seq, 0, sizeof(uint32_t), st);
+        for (uint32_t y = 0; y < nseq; ++y) {
+            if (total) (void)hipMemsetAsync(total + (size_t)y * counter_stride, 0, sizeof(uint32_t), st);
+            if (out_seq) (void)hipMemsetAsync(out_seq + y, 0, sizeof(uint32_t), st);
+        }
         return GSR_OK;
     }
     if (!in || !out) { gsr_set_error("gsr_exclusive_scan: null pointer"); return GSR_ERR_ARG; }
     uint32_t *sums = (uint32_t *)workspace;
     const uint32_t nb = gsr_div_up(n, SCAN_TILE);
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, n, sums, overflow_flag);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb, total, overflow_flag);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, idx, out, n, sums, out_seq);
+    const SegCounters cnt = {total, overflow_flag, counter_stride};
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb, nseq), dim3(SCAN_THREADS), 0, st, in, idx, n, sums, cnt);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1, nseq), dim3(1024), 0, st, sums, nb, cnt);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb, nseq), dim3(SCAN_THREADS), 0, st, in, idx, out, n, sums, out_seq);
     return gsr_check_launch("exclusive_scan");
+}
+
+int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
+                             void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq,
+                             uint32_t *overflow_flag)
+{
+    return gsr_exclusive_scan_along_batch(in, idx, out, n, 1, total, overflow_flag, 0, workspace, workspace_bytes, stream, out_seq);
 }
 
 extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *workspace,
@@ -413,9 +454,11 @@ extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)
 
 // Sorts between the two buffer pairs; *result_in_first tells where the sorted data ended up (the
 // *_a buffers after an even number of passes).  No copies.
+// (nseq independent sequences of n pairs each, one after the other in all four buffers; the workspace holds
+// nseq times gsr_sort_workspace_bytes(n))
 template <typename V>
 static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_b, uint32_t n, int begin_bit, int end_bit,
-                         void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first)
+                         void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first, uint32_t nseq = 1)
 {
     hipStream_t st = (hipStream_t)stream;
     *result_in_first = true;
@@ -423,25 +466,33 @@ static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_
         gsr_set_error("gsr_sort_pairs: bad bit range [%d,%d)", begin_bit, end_bit);
         return GSR_ERR_ARG;
     }
-    if (workspace_bytes < gsr_sort_workspace_bytes(n) || !workspace) {
-        gsr_set_error("gsr_sort_pairs: workspace too small (%zu < %zu)", workspace_bytes, gsr_sort_workspace_bytes(n));
+    if (workspace_bytes < nseq * gsr_sort_workspace_bytes(n) || !workspace) {
+        gsr_set_error("gsr_sort_pairs: workspace too small (%zu < %zu)", workspace_bytes, nseq * gsr_sort_workspace_bytes(n));
         return GSR_ERR_ARG;
     }
-    if (n == 0) return GSR_OK;
+    if (n == 0 || nseq == 0) return GSR_OK;
     if (!keys_a || !vals_a || !keys_b || !vals_b) { gsr_set_error("gsr_sort_pairs: null pointer"); return GSR_ERR_ARG; }
     const uint32_t nb = gsr_div_up(n, SORT_TILE);
     uint32_t *hist = (uint32_t *)workspace;
-    const size_t hist_bytes = align256((size_t)nb * RADIX_SIZE * sizeof(uint32_t));
-    uint32_t *digit_total = (uint32_t *)((char *)workspace + hist_bytes);
+    const size_t hist_bytes = align256((size_t)nseq * nb * RADIX_SIZE * sizeof(uint32_t));
+    uint32_t *digit_total = (uint32_t *)((char *)workspace + hist_bytes);   // nseq * 256 words
     uint32_t *ki = keys_a, *ko = keys_b;
     V *vi = vals_a, *vo = vals_b;
+    // 32-bit values: one launch over a few million keys is bound by its scattered 4-byte writes and gains from
+    // putting a block's keys in digit order in LDS first (8 x 1 M keys: 0.87 -> 0.68 ms for the four passes); a
+    // single million is bound by latency and loses (see radix_scatter_kernel)
+    const bool staged32 = (unsigned long long)n * nseq >= 3000000ull;
     for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
         const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
         const uint32_t mask = (1u << nbits) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
-        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE), dim3(256), 0, st, hist, nb, digit_total);
-        hipLaunchKernelGGL((radix_scatter_kernel<V, (sizeof(V) > 4)>), dim3(nb), dim3(SORT_THREADS), 0, st, ki, vi, ko,
-                           vo, n, bit, mask, nb, hist, digit_total);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
+        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE, nseq), dim3(256), 0, st, hist, nb, digit_total);
+        if (sizeof(V) > 4 || staged32)
+            hipLaunchKernelGGL((radix_scatter_kernel<V, true>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, vi, ko,
+                               vo, n, bit, mask, nb, hist, digit_total);
+        else
+            hipLaunchKernelGGL((radix_scatter_kernel<V, false>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, vi, ko,
+                               vo, n, bit, mask, nb, hist, digit_total);
         uint32_t *t = ki; ki = ko; ko = t;
         V *tv = vi; vi = vo; vo = tv;
         *result_in_first = !*result_in_first;
@@ -455,6 +506,13 @@ int gsr_sort_pingpong32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, ui
 {
     return sort_pingpong<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, workspace, workspace_bytes,
                                    stream, result_in_first);
+}
+int gsr_sort_pingpong32_batch(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, uint32_t nseq,
+                              int begin_bit, int end_bit, void *workspace, size_t workspace_bytes, void *stream,
+                              bool *result_in_first)
+{
+    return sort_pingpong<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, workspace, workspace_bytes,
+                                   stream, result_in_first, nseq);
 }
 int gsr_sort_pingpong64(uint32_t *keys_a, uint64_t *vals_a, uint32_t *keys_b, uint64_t *vals_b, uint32_t n, int begin_bit,
                         int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first)

@@ -185,6 +185,76 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
     return st
 
 
+def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views) -> list:
+    """``forward_begin`` for several views of the same Gaussians (at most ``_lib.MAX_VIEWS`` per call; more are
+    taken in groups): ONE pass over the parameters for stage 1 of all of them, ONE set of launches for their depth
+    orders and ONE read-back of all counters.  Returns one ``RenderState`` per view, the same - bit for bit - as
+    ``forward_begin`` leaves (their arrays are slices of arrays that hold all views)."""
+    lib = _lib.load()
+    views = list(views)
+    if len(views) > _lib.MAX_VIEWS:
+        out = []
+        for k in range(0, len(views), _lib.MAX_VIEWS):
+            out += forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views[k:k + _lib.MAX_VIEWS])
+        return out
+    if len(views) == 1:
+        return [forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, None, views[0])]
+    dev = coords.device
+    n = coords.shape[0]
+    nv = len(views)
+    coords = _check_param("coords", coords, (3,))
+    scale_raw = _check_param("scale", scale_raw, (3,), n)
+    rot_raw = _check_param("rotation", rot_raw, (4,), n)
+    if opac_raw.dim() == 1:
+        opac_raw = opac_raw.unsqueeze(1)
+    opac_raw = _check_param("opacity", opac_raw, (1,), n)
+    sh = _check_param("sh", sh, (3, 16), n)
+    stream = _stream(dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    cviews = (_lib.GsrView * nv)(*[_lib.make_view(n, v.sh_degree, v.width, v.height, v.tile_length, v.w2m, v.proj, v.cam_pos)
+                                   for v in views])
+    mask = torch.empty(nv, n, dtype=torch.uint8, device=dev)
+    depth_key = torch.empty(nv, n, **i32)
+    pos2d = torch.empty(nv, n, 3, **f32)
+    cov2d = torch.empty(nv, n, 4, **f32)
+    radius = torch.empty(nv, n, **f32)
+    bbox = torch.empty(nv, n, 4, **i32)
+    ntiles = torch.empty(nv, n, **i32)
+    rec = torch.empty(nv, n, _lib.REC_FLOATS, **f32)
+    counters = torch.zeros(nv, 8, **i32)
+    _call("gsr_preprocess_fwd_views", lib.gsr_preprocess_fwd_views, cviews, nv, _ptr(coords), _ptr(scale_raw), _ptr(rot_raw),
+          _ptr(opac_raw), _ptr(sh), _ptr(mask), _ptr(depth_key), _ptr(pos2d), _ptr(cov2d), _ptr(radius), _ptr(bbox),
+          _ptr(ntiles), _ptr(rec), _ptr(counters), stream)
+    order = torch.empty(nv, n, **i32)
+    slot_base = torch.empty(nv, n, **i32)
+    slot_seq = torch.empty(nv, n + 1, **i32)
+    ws_bytes = int(lib.gsr_bin_offsets_views_workspace_bytes(n, nv))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _call("gsr_bin_offsets_views", lib.gsr_bin_offsets_views, _ptr(depth_key), _ptr(ntiles), n, nv, _ptr(order), _ptr(slot_base),
+          _ptr(slot_seq), _ptr(counters), _ptr(ws), ws_bytes, stream)
+    main = torch.cuda.current_stream(dev)
+    side = _copy_stream(dev)
+    done = torch.cuda.Event()
+    done.record(main)
+    host = torch.empty(nv, 8, dtype=torch.int32, pin_memory=True)
+    ready = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        side.wait_event(done)
+        host.copy_(counters, non_blocking=True)
+        ready.record(side)
+    states = []
+    for k in range(nv):
+        st = RenderState()
+        st.view, st.n, st.cview = views[k], n, cviews[k]
+        st.mask_u8, st.pos2d, st.cov2d, st.radius_full = mask[k], pos2d[k], cov2d[k], radius[k]
+        st.bbox, st.ntiles, st.rec = bbox[k], ntiles[k], rec[k]
+        st.order, st.slot_base, st.slot_seq = order[k], slot_base[k], slot_seq[k]
+        st._counters, st._host, st._ready = counters, host[k], ready
+        states.append(st)
+    return states
+
+
 def forward_lists(st: RenderState) -> RenderState:
     """Waits for the view's counters (the one synchronisation of a render), sizes the per-pair
     buffers and builds the per-tile lists, the record stream and the tile order."""
@@ -197,7 +267,8 @@ def forward_lists(st: RenderState) -> RenderState:
     st._ready.synchronize()
     host = st._host
     st.num_visible, st.num_pairs, err = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2])
-    _pinned_pool.append(host)
+    if host._base is None:
+        _pinned_pool.append(host)          # (a row of the buffer that several views share is not recycled)
     st._host = st._counters = st._ready = None
     if err & 1:
         raise SingularCovarianceError("singular 2-D covariance in a Gaussian that lands in a tile")

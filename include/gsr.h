@@ -94,6 +94,18 @@ int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const flo
                        float *pos2d, float *cov2d, float *radius, int32_t *bbox, uint32_t *ntiles,
                        float *rec, gsr_counters *counters, void *stream);
 
+/* gsr_preprocess_fwd for num_views (1..8) views of the SAME Gaussians in one pass over the parameters - the
+ * views of one optimisation step (Trainer.py:54-57 renders one; a view minibatch renders several against the
+ * same model).  The parameters are read once and the view-independent statements (GaussianModel.py:42-65,
+ * 99-108) are evaluated once; per view the results equal gsr_preprocess_fwd's bit for bit.  views_host: the
+ * views (same n and sh degree).  Every output array holds the views one after the other: view k's rows
+ * start k * n rows in (mask[num_views*N], pos2d[num_views*N,3], ...); counters[num_views].  screen_coords
+ * are taken as zeros. */
+int gsr_preprocess_fwd_views(const gsr_view *views_host, uint32_t num_views, const float *coords,
+                             const float *scale_raw, const float *rot_raw, const float *opac_raw, const float *sh,
+                             uint8_t *mask, uint32_t *depth_key, float *pos2d, float *cov2d, float *radius,
+                             int32_t *bbox, uint32_t *ntiles, float *rec, gsr_counters *counters, void *stream);
+
 /* Backward of stage 1.  Replaces the autograd graph of the statements listed above
  * (Trainer.py:57).  pairgrad (written by gsr_composite_bwd for the same view) holds the gradient records of
  * the (tile, Gaussian) pairs at their emission slots: Gaussian g owns the contiguous slots
@@ -191,6 +203,16 @@ size_t gsr_bin_offsets_workspace_bytes(uint32_t n);
 int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uint32_t *order,
                     uint32_t *slot_base, uint32_t *slot_seq, gsr_counters *counters, void *workspace,
                     size_t workspace_bytes, void *stream);
+
+/* gsr_bin_offsets for num_views views of the same n Gaussians with one set of launches (the arrays of
+ * gsr_preprocess_fwd_views: view k's depth_key / ntiles / order / slot_base start k * n elements in, its
+ * slot_seq k * (n + 1), its counters at counters[k]).  Per view the results equal gsr_bin_offsets' bit for
+ * bit.  Replaces, like gsr_bin_offsets, the depth argsort of GaussianRenderer.py:89-97 - for all views of a
+ * step at once.  workspace: gsr_bin_offsets_views_workspace_bytes(n, num_views). */
+size_t gsr_bin_offsets_views_workspace_bytes(uint32_t n, uint32_t num_views);
+int gsr_bin_offsets_views(uint32_t *depth_key, const uint32_t *ntiles, uint32_t n, uint32_t num_views, uint32_t *order,
+                          uint32_t *slot_base, uint32_t *slot_seq, gsr_counters *counters, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /* Per-tile lists.  order, slot_base and slot_seq (may be NULL) come from gsr_bin_offsets; num_pairs
  * must be the value read back from counters->num_pairs.

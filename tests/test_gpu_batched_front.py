@@ -1,0 +1,89 @@
+"""GPU: stage 1 and the depth order of several views in one pass (gsr_preprocess_fwd_views, gsr_bin_offsets_views)
+leave, for every view, exactly what the one-view entry points leave - every array bit for bit, counters included -
+and a minibatch rendered through them gives bit-identical images and gradients."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("mask_u8", "pos2d", "cov2d", "radius_full", "bbox", "ntiles", "rec", "order", "slot_base", "slot_seq")
+
+
+def _scene(n, w, h, deg, nviews, seed=0):
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.camera import Camera
+    from gsplat_amd.rasterizer import ViewSpec
+    from gsplat_amd.scenes import synthetic_scene
+    dev = torch.device("cuda", 0)
+    sc = synthetic_scene(n, w, h, deg, seed=seed)
+    params = [t.to(dev) for t in sc.params()]
+    views = []
+    for v in range(nviews):
+        ang = 2.0 * np.pi * v / max(nviews, 1)
+        pos = np.array([0.15 * np.cos(ang), 0.15 * np.sin(ang), 0.0])
+        views.append(ViewSpec.from_camera(Camera(pos, np.array([1.0, 0.0, 0.0, 0.0]), sc.fx, sc.fy, w / 2, h / 2, w, h, device=dev), deg, 16))
+    return dev, params, views
+
+
+def _same(a, b, what):
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert a.shape == b.shape, what
+    assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{what} differs"
+
+
+@pytest.mark.parametrize("n,w,h,deg,nviews", [(3000, 200, 120, 3, 3), (70_001, 640, 360, 2, 8), (5, 64, 48, 0, 2),
+                                               (200_000, 800, 800, 3, 11)])
+def test_batched_front_equals_the_one_view_calls(n, w, h, deg, nviews):
+    from gsplat_amd import rasterizer as R
+    dev, params, views = _scene(n, w, h, deg, nviews)
+    batched = R.forward_begin_views(*params, views)
+    assert len(batched) == nviews
+    for k, view in enumerate(views):
+        single = R.forward_begin(*params, None, view)
+        R.forward_lists(single)
+        R.forward_lists(batched[k])
+        assert (batched[k].num_visible, batched[k].num_pairs) == (single.num_visible, single.num_pairs), k
+        for f in FIELDS:
+            _same(getattr(batched[k], f), getattr(single, f), f"view {k}: {f}")
+        if single.num_visible:
+            _same(batched[k].tile_offsets, single.tile_offsets, f"view {k}: tile_offsets")
+            _same(batched[k].sorted_gauss[:single.num_pairs], single.sorted_gauss[:single.num_pairs], f"view {k}: lists")
+            _same(batched[k].stream_rec[:single.num_pairs], single.stream_rec[:single.num_pairs], f"view {k}: stream")
+
+
+def test_minibatch_with_batched_front_is_bit_identical():
+    from gsplat_amd.minibatch import render_views
+    dev, params, views = _scene(150_000, 640, 480, 3, 5, seed=3)
+    gen = torch.Generator().manual_seed(5)
+    cots = [torch.rand(640, 480, 3, generator=gen).to(dev) for _ in views]
+    out = {}
+    for batch in (False, True):
+        states, grads, g_screens = render_views(params, views, lambda i, st: cots[i], batch_front=batch)
+        torch.cuda.synchronize()
+        out[batch] = ([st.img.clone() for st in states], [g.clone() for g in grads], [g.clone() for g in g_screens])
+    for a, b in zip(out[False][0] + out[False][1] + out[False][2], out[True][0] + out[True][1] + out[True][2]):
+        _same(a, b, "minibatch output")
+
+
+def test_batched_front_refuses_mixed_views():
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd import _lib
+    dev, params, views = _scene(100, 64, 48, 1, 2)
+    lib = _lib.load()
+    cv = (_lib.GsrView * 2)(_lib.make_view(100, 1, 64, 48, 16, views[0].w2m, views[0].proj, views[0].cam_pos),
+                             _lib.make_view(100, 2, 64, 48, 16, views[1].w2m, views[1].proj, views[1].cam_pos))
+    t = torch.zeros(4096, dtype=torch.float32, device=dev)
+    assert lib.gsr_preprocess_fwd_views(cv, 2, *params_ptrs(params), *[t.data_ptr()] * 9, torch.cuda.current_stream().cuda_stream) != 0
+    assert b"differs" in lib.gsr_last_error()
+    assert lib.gsr_preprocess_fwd_views(cv, 9, *params_ptrs(params), *[t.data_ptr()] * 9, torch.cuda.current_stream().cuda_stream) != 0
+
+
+def params_ptrs(params):
+    return [p.contiguous().data_ptr() for p in params]

@@ -37,7 +37,7 @@ def test_exclusive_scan(n):
 
 @pytest.mark.parametrize("n,bits,distinct", [(0, 32, 10), (1, 32, 10), (4095, 32, 1 << 30), (4096, 13, 8160),
                                              (4097, 32, 50), (1_000_003, 32, 1 << 31), (2_500_000, 15, 32400),
-                                             (300_000, 0, 5), (70_000, 9, 400)])
+                                             (300_000, 0, 5), (70_000, 9, 400), (3_200_001, 32, 1 << 31)])
 def test_sort_pairs_is_a_stable_radix_sort(n, bits, distinct):
     L, lib = _lib()
     dev = torch.device("cuda:0")
