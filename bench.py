@@ -61,9 +61,12 @@ def algorithmic_bytes(n, m, pairs, pixels, k_sh, views=1, parts=1):
     k_sh active SH coefficients per channel.  All per view, except "preprocess_bwd_views": ONE launch chains the
     per-Gaussian sums of `views` views to the raw parameters - it reads the parameters and writes the dense
     gradients once per step, and reads 48 bytes of sums + the mask and writes the 12-byte screen gradient per view.
-    "pair_reduce" reads the per-pair gradient records (48 bytes, `parts` rows per pair) and writes the sums."""
+    "pair_reduce" reads the per-pair gradient records (48 bytes, `parts` rows per pair) and writes the sums.
+    "preprocess_fwd_views" is stage 1 of all `views` views in ONE launch (the parameters are read once), here
+    divided by the number of views so that it compares with a per-view time."""
     return {
         "preprocess_fwd": n * (12 + 12 + 16 + 4 + 12 * k_sh) + n + m * 64,
+        "preprocess_fwd_views": (n * (12 + 12 + 16 + 4 + 12 * k_sh) + views * (n + m * 64)) / max(views, 1),
         "binning_sort": m * 16 + pairs * 12 + 2 * pairs * 12 + pairs * 8,
         "composite_fwd": pairs * (4 + 40) + pixels * 12 + pixels * 4,
         "composite_bwd": pairs * 44 + pixels * (12 + 12 + 8) + m * 40,
@@ -318,8 +321,9 @@ def main():
                 "avg_launch_ms_alone": None if dom_alone_ms is None else round(dom_alone_ms, 4),
                 "note": "compositing is bound by vector instruction issue at these list lengths (SQ counters: profiles/r02a_pmc_composite_sq.txt), not by HBM; "
                         "traffic = HBM-side bytes of one launch of this kernel on this workload's first view from the PMC passes under profiles/ (traffic.json); avg_launch_ms is measured in "
-                        "the timed region, where the next view's stage 1, sorts and lists run beside the kernel on a second "
-                        "stream and share the CUs with it (avg_launch_ms_alone: the same launch with nothing beside it)",
+                        "the timed region, where the next view's pair emission, tile sort and record stream run beside the kernel on a second "
+                        "stream and share the CUs with it (avg_launch_ms_alone: the same launch with nothing beside it); "
+                        "stage 1 and the depth sort of all views of the step are one set of launches (stages *_views, per view here)",
             },
             "stage_ms_per_view": {k: round(v, 4) for k, v in stage_ms.items()},
             "exchange_ms_per_step": None if exchange_ms is None else round(exchange_ms, 4),
@@ -327,7 +331,7 @@ def main():
             # step for all views of the rank: its bytes and its time are both per step
             "stage_hbm_frac": dict(
                 [(k, round(ab[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-                 for k in ("preprocess_fwd", "composite_fwd", "composite_bwd", "pair_reduce") if stage_ms.get(k, 0.0) > 0.0] +
+                 for k in ("preprocess_fwd", "preprocess_fwd_views", "composite_fwd", "composite_bwd", "pair_reduce") if stage_ms.get(k, 0.0) > 0.0] +
                 [("preprocess_bwd_views", round(ab["preprocess_bwd_views"] / (stage_ms["preprocess_bwd_views"] * max(len(views), 1) * 1e-3)
                                                 / 1e9 / HBM_PEAK_GBS, 4))] if stage_ms.get("preprocess_bwd_views", 0.0) > 0.0 else []),
         }
