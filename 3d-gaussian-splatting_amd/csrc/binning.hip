@@ -6,6 +6,8 @@
 // (tile id, depth bits): the four depth digits are sorted once per Gaussian - they are equal for
 // all tiles a Gaussian touches - and the tile digits once per (tile, Gaussian) pair.  Both sorts
 // are stable and pairs are emitted in depth order, so ties in depth keep ascending Gaussian index.
+#include <stdlib.h>
+
 #include "gsr_common.hpp"
 
 namespace {
@@ -15,6 +17,17 @@ __global__ void iota_kernel(uint32_t *__restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[(size_t)blockIdx.y * n + i] = i;
+}
+
+// A (tile, Gaussian, slot) triple in one 64-bit word: slot in the low `slot` bits, the Gaussian above it, the
+// tile id above that.  The tile sort then moves 8 bytes per pair and pass instead of a 4-byte key and an
+// 8-byte value.  Used whenever the three fields fit 64 bits (gsr_bin_lists decides).
+struct PairBits {
+    int slot, gauss;   // widths; the tile id starts at bit slot + gauss
+};
+__device__ inline uint64_t pack_pair(PairBits b, uint32_t tile, uint32_t gauss, uint32_t slot)
+{
+    return ((uint64_t)tile << (b.slot + b.gauss)) | ((uint64_t)gauss << b.slot) | (uint64_t)slot;
 }
 
 // Emits (tile id, owner | slot) for every slot.  Slot e of Gaussian g: e = slot_base[g] + (xi - x0) * ny
@@ -30,7 +43,8 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
                                                          const int32_t *__restrict__ bbox,
                                                          const uint32_t *__restrict__ ntiles,
                                                          uint32_t *__restrict__ tile_key,
-                                                         uint64_t *__restrict__ owner_slot, uint32_t num_pairs)
+                                                         uint64_t *__restrict__ owner_slot, uint32_t num_pairs,
+                                                         PairBits bits)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;   // position in depth order
     uint32_t g = 0, sb = 0xFFFFFFFFu, nt = 0;
@@ -76,8 +90,13 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
         if (pos < end) {
             const uint32_t local = pos - osb;
             const uint32_t cx = local / (uint32_t)ony, cy = local - cx * (uint32_t)ony;
-            tile_key[pos] = (uint32_t)(oy0 + (int)cy + v.nbh * (ox0 + (int)cx));
-            owner_slot[pos] = ((uint64_t)og << 32) | (uint64_t)pos;   // carried through the tile sort
+            const uint32_t tile = (uint32_t)(oy0 + (int)cy + v.nbh * (ox0 + (int)cx));
+            if (tile_key) {
+                tile_key[pos] = tile;
+                owner_slot[pos] = ((uint64_t)og << 32) | (uint64_t)pos;   // carried through the tile sort
+            } else {
+                owner_slot[pos] = pack_pair(bits, tile, og, pos);          // one word per pair, sorted by its tile bits
+            }
         }
     }
 }
@@ -122,8 +141,9 @@ __device__ inline bool tile_all_clamped_low(float gx, float gy, float A, float B
 __global__ __launch_bounds__(256) void finalize_lists_kernel(
     ViewK v, const uint32_t *__restrict__ sorted_tile, const uint64_t *__restrict__ sorted_owner_slot,
     const float *__restrict__ rec, uint32_t num_pairs, uint32_t T, uint32_t *__restrict__ tile_offsets,
-    uint32_t *__restrict__ pair_slot, uint32_t *__restrict__ sorted_gauss, float *__restrict__ stream_rec)
+    uint32_t *__restrict__ pair_slot, uint32_t *__restrict__ sorted_gauss, float *__restrict__ stream_rec, PairBits bits)
 {
+    // (sorted_tile == null: sorted_owner_slot holds packed words, see pack_pair)
     // The 64-byte records of a wave's 64 pairs are one contiguous 4 KiB piece of the stream: they go
     // through LDS so that every store instruction writes 1 KiB of consecutive addresses.
     __shared__ float4 tile[256 * 4];
@@ -135,13 +155,15 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
     float4 out[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
                      make_float4(0.f, 0.f, 0.f, 0.f)};
     if (p < num_pairs) {
-    const uint64_t os = sorted_owner_slot[p];
-    const uint32_t g = (uint32_t)(os >> 32);
-    if (pair_slot) pair_slot[p] = (uint32_t)os;
+    const uint64_t word = sorted_owner_slot[p];
+    const bool packed = sorted_tile == nullptr;
+    const uint32_t g = packed ? (uint32_t)(word >> bits.slot) & ((1u << bits.gauss) - 1u) : (uint32_t)(word >> 32);
+    const uint32_t slot = packed ? (uint32_t)word & (uint32_t)((1ull << bits.slot) - 1ull) : (uint32_t)word;
+    if (pair_slot) pair_slot[p] = slot;
     sorted_gauss[p] = g;
     const float4 *src = reinterpret_cast<const float4 *>(rec + (size_t)g * GSR_REC_FLOATS);
     const float4 a = src[0], b = src[1], c = src[2];   // x y A' B' | D' o r g | b ca cbh cd
-    const uint32_t cur = sorted_tile[p];
+    const uint32_t cur = packed ? (uint32_t)(word >> (bits.slot + bits.gauss)) : sorted_tile[p];
     uint32_t flags;
     {
         const int xi = (int)(cur / (uint32_t)v.nbh), yi = (int)(cur - (uint32_t)xi * v.nbh);
@@ -171,9 +193,9 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
     // stream layout: y x D' A' | o B' r ca | g slot b flags | cbh 0 cd 0
     out[0] = make_float4(a.y, a.x, b.x, a.z);
     out[1] = make_float4(b.y, a.w, b.z, c.y);
-    out[2] = make_float4(b.w, __uint_as_float((uint32_t)os), c.x, __uint_as_float(flags));
+    out[2] = make_float4(b.w, __uint_as_float(slot), c.x, __uint_as_float(flags));
     out[3] = make_float4(c.z, 0.0f, c.w, 0.0f);
-    const uint32_t first = p == 0 ? 0u : sorted_tile[p - 1] + 1u;
+    const uint32_t first = p == 0 ? 0u : (packed ? (uint32_t)(sorted_owner_slot[p - 1] >> (bits.slot + bits.gauss)) : sorted_tile[p - 1]) + 1u;
     for (uint32_t t = first; t <= cur; ++t) tile_offsets[t] = p;  // tiles (prev, cur] start at p
     if (p + 1 == num_pairs)
         for (uint32_t t = cur + 1; t <= T; ++t) tile_offsets[t] = num_pairs;
@@ -192,6 +214,14 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// GSR_WIDE_PAIRS=1 in the environment keeps the (32-bit key, 64-bit value) form of the pairs even when the packed
+// word would fit - the form that workloads with very many tiles, Gaussians and pairs fall back to, kept testable.
+inline bool gsr_force_wide_pairs()
+{
+    const char *e = getenv("GSR_WIDE_PAIRS");   // read at every call: a test switches it inside one process
+    return e && e[0] == '1';
+}
 
 inline int bits_for(uint32_t count)
 {
@@ -393,14 +423,30 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, c
     uint64_t *sorted_owner_slot = (uint64_t *)(ws + 4 * arr);
     void *sort_ws = ws + 6 * arr;
     const size_t sort_bytes = workspace_bytes - 6 * arr;
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, order, slot_seq, slot_base,
-                       bbox, ntiles, tile_key, owner_slot, num_pairs);
+    // One word per pair whenever tile, Gaussian and slot fit 64 bits together (1 M Gaussians at 1080p: 13 + 20 + 23;
+    // 6 M at 2160p: 15 + 23 + 25), else a 32-bit tile key beside a 64-bit (Gaussian, slot) value.
+    const PairBits bits = {bits_for(num_pairs), bits_for((uint32_t)v.n)};
+    const int tile_bits = bits_for((uint32_t)v.T);
+    const bool packed = bits.slot + bits.gauss + tile_bits <= 64 && bits.gauss < 32 && bits.slot < 32 && !gsr_force_wide_pairs();
     bool in_first;
-    if (int e = gsr_sort_pingpong64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0,
-                                    bits_for((uint32_t)v.T), sort_ws, sort_bytes, stream, &in_first))
+    if (packed) {
+        hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, order, slot_seq, slot_base,
+                           bbox, ntiles, (uint32_t *)nullptr, owner_slot, num_pairs, bits);
+        if (int e = gsr_sort_words64(owner_slot, sorted_owner_slot, num_pairs, bits.slot + bits.gauss,
+                                     bits.slot + bits.gauss + tile_bits, sort_ws, sort_bytes, stream, &in_first))
+            return e;
+        hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
+                           (const uint32_t *)nullptr, in_first ? owner_slot : sorted_owner_slot, rec, num_pairs, (uint32_t)v.T,
+                           tile_offsets, pair_slot, sorted_gauss, stream_rec, bits);
+        return gsr_check_launch("bin_lists");
+    }
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, order, slot_seq, slot_base,
+                       bbox, ntiles, tile_key, owner_slot, num_pairs, bits);
+    if (int e = gsr_sort_pingpong64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0, tile_bits, sort_ws,
+                                    sort_bytes, stream, &in_first))
         return e;
     hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
                        in_first ? tile_key : sorted_tile, in_first ? owner_slot : sorted_owner_slot, rec, num_pairs,
-                       (uint32_t)v.T, tile_offsets, pair_slot, sorted_gauss, stream_rec);
+                       (uint32_t)v.T, tile_offsets, pair_slot, sorted_gauss, stream_rec, bits);
     return gsr_check_launch("bin_lists");
 }

@@ -27,6 +27,8 @@ int gsr_sort_pingpong32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, ui
                         int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
 int gsr_sort_pingpong64(uint32_t *keys_a, uint64_t *vals_a, uint32_t *keys_b, uint64_t *vals_b, uint32_t n, int begin_bit,
                         int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
+int gsr_sort_words64(uint64_t *words_a, uint64_t *words_b, uint32_t n, int begin_bit, int end_bit, void *workspace,
+                     size_t workspace_bytes, void *stream, bool *result_in_first);   // 64-bit words by their own bits
 int gsr_sort_pingpong32_batch(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, uint32_t nseq,
                               int begin_bit, int end_bit, void *workspace, size_t workspace_bytes, void *stream,
                               bool *result_in_first);   // nseq sequences of n pairs, one after the other

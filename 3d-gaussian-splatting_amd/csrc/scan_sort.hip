@@ -166,8 +166,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
 
 // ---- radix sort -------------------------------------------------------------------------
 
-// hist[digit * nb + block] = number of keys of the block's tile with that digit
-__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n,
+// hist[digit * nb + block] = number of keys of the block's tile with that digit.
+// K = uint32_t: the keys of a (key, value) sort; K = uint64_t: 64-bit words sorted by some of their own bits.
+template <typename K>
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const K *__restrict__ keys, uint32_t n,
                                                                   int shift, uint32_t mask, uint32_t nb,
                                                                   uint32_t *__restrict__ hist)
 {
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const uint32_t i = base + it * SORT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
     hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
@@ -217,7 +219,11 @@ __global__ __launch_bounds__(256) void radix_rows_kernel(uint32_t *__restrict__ 
 // (STAGED = false writes straight from registers: for digits that are spread evenly over the 256
 // values - the depth bits - a digit's run inside a tile is only ~16 items and the detour through LDS
 // does not pay.)
-template <typename V, bool STAGED>
+template <typename V>
+__device__ inline uint32_t word_key(V word, int shift) { return (uint32_t)((unsigned long long)word >> shift); }
+
+// WORDS (V = uint64_t, STAGED): there is no key array - the digit is taken from bits shift.. of the value itself.
+template <typename V, bool STAGED, bool WORDS = false>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     V *__restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nb,
@@ -230,8 +236,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     __shared__ V stage[STAGED ? SORT_TILE : 1];        // keys (as words), then values, in digit order
     uint32_t *stage_keys = reinterpret_cast<uint32_t *>(stage);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    keys_in += (size_t)blockIdx.y * n; vals_in += (size_t)blockIdx.y * n;
-    keys_out += (size_t)blockIdx.y * n; vals_out += (size_t)blockIdx.y * n;
+    if (!WORDS) { keys_in += (size_t)blockIdx.y * n; keys_out += (size_t)blockIdx.y * n; }
+    vals_in += (size_t)blockIdx.y * n; vals_out += (size_t)blockIdx.y * n;
+    const int word_shift = shift;   // WORDS: position of the digit inside the 64-bit word
+    if (WORDS) shift = 0;
     hist_rows += (size_t)blockIdx.y * RADIX_SIZE * nb;
     digit_total += (size_t)blockIdx.y * RADIX_SIZE;
     // first position of digit d in the output: exclusive scan of the 256 digit totals
@@ -254,7 +262,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const uint32_t i = wbase + it * 64 + lane;
         const bool valid = i < n;
-        key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        // (WORDS: the 32 bits of the word from its digit on; the code below then finds the digit at bit 0)
+        key[it] = valid ? (WORDS ? word_key(vals_in[i], word_shift) : keys_in[i]) : 0xFFFFFFFFu;
         const uint32_t d = (key[it] >> shift) & mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
             const uint32_t k = stage_keys[l];
             const uint32_t d = (k >> shift) & mask;
             gpos[it] = gbase[d] + (l - lstart[d]);
-            keys_out[gpos[it]] = k;
+            if (!WORDS) keys_out[gpos[it]] = k;
         }
     }
     __syncthreads();
@@ -485,7 +494,7 @@ static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_
     for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
         const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
         const uint32_t mask = (1u << nbits) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
+        hipLaunchKernelGGL(radix_hist_kernel<uint32_t>, dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
         hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE, nseq), dim3(256), 0, st, hist, nb, digit_total);
         if (sizeof(V) > 4 || staged32)
             hipLaunchKernelGGL((radix_scatter_kernel<V, true>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, vi, ko,
@@ -498,6 +507,39 @@ static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_
         *result_in_first = !*result_in_first;
     }
     return gsr_check_launch("sort_pairs");
+}
+
+// 64-bit words sorted (stably) by their bits [begin_bit, end_bit): ping-pong between words_a and words_b as above.
+int gsr_sort_words64(uint64_t *words_a, uint64_t *words_b, uint32_t n, int begin_bit, int end_bit, void *workspace,
+                     size_t workspace_bytes, void *stream, bool *result_in_first)
+{
+    hipStream_t st = (hipStream_t)stream;
+    *result_in_first = true;
+    if (begin_bit < 0 || end_bit > 64 || begin_bit > end_bit) {
+        gsr_set_error("gsr_sort_words64: bad bit range [%d,%d)", begin_bit, end_bit);
+        return GSR_ERR_ARG;
+    }
+    if (workspace_bytes < gsr_sort_workspace_bytes(n) || !workspace) {
+        gsr_set_error("gsr_sort_words64: workspace too small (%zu < %zu)", workspace_bytes, gsr_sort_workspace_bytes(n));
+        return GSR_ERR_ARG;
+    }
+    if (n == 0) return GSR_OK;
+    if (!words_a || !words_b) { gsr_set_error("gsr_sort_words64: null pointer"); return GSR_ERR_ARG; }
+    const uint32_t nb = gsr_div_up(n, SORT_TILE);
+    uint32_t *hist = (uint32_t *)workspace;
+    uint32_t *digit_total = (uint32_t *)((char *)workspace + align256((size_t)nb * RADIX_SIZE * sizeof(uint32_t)));
+    uint64_t *wi = words_a, *wo = words_b;
+    for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
+        const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
+        const uint32_t mask = (1u << nbits) - 1u;
+        hipLaunchKernelGGL(radix_hist_kernel<uint64_t>, dim3(nb), dim3(SORT_THREADS), 0, st, wi, n, bit, mask, nb, hist);
+        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE), dim3(256), 0, st, hist, nb, digit_total);
+        hipLaunchKernelGGL((radix_scatter_kernel<uint64_t, true, true>), dim3(nb), dim3(SORT_THREADS), 0, st,
+                           (const uint32_t *)nullptr, wi, (uint32_t *)nullptr, wo, n, bit, mask, nb, hist, digit_total);
+        uint64_t *t = wi; wi = wo; wo = t;
+        *result_in_first = !*result_in_first;
+    }
+    return gsr_check_launch("sort_words64");
 }
 
 // library-internal entry points (binning.hip): sort without the final copy

@@ -87,3 +87,27 @@ def test_batched_front_refuses_mixed_views():
 
 def params_ptrs(params):
     return [p.contiguous().data_ptr() for p in params]
+
+
+@pytest.mark.parametrize("n,w,h,deg,tile", [(60_000, 640, 360, 1, 16), (20_000, 300, 200, 2, 64)])
+def test_packed_pair_words_and_wide_pairs_build_the_same_lists(n, w, h, deg, tile):
+    """The list builder sorts one 64-bit word per pair when tile, Gaussian and slot fit one (the normal case) and a
+    32-bit key beside a 64-bit value otherwise; GSR_WIDE_PAIRS=1 forces the latter.  Both give the same lists,
+    record stream and tile offsets, bit for bit."""
+    from gsplat_amd import rasterizer as R
+    dev, params, views = _scene(n, w, h, deg, 1)
+    view = R.ViewSpec(views[0].sh_degree, w, h, tile, views[0].w2m, views[0].proj, views[0].cam_pos)
+    out = {}
+    for wide in ("0", "1"):
+        os.environ["GSR_WIDE_PAIRS"] = wide
+        try:
+            st = R.forward_pipeline(*params, None, view)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("GSR_WIDE_PAIRS", None)
+        out[wide] = st
+    a, b = out["0"], out["1"]
+    assert a.num_pairs == b.num_pairs > 0
+    for f in ("tile_offsets", "sorted_gauss", "stream_rec", "img", "final_T"):
+        _same(getattr(a, f)[:a.num_pairs] if f in ("sorted_gauss", "stream_rec") else getattr(a, f),
+              getattr(b, f)[:a.num_pairs] if f in ("sorted_gauss", "stream_rec") else getattr(b, f), f)
