@@ -111,3 +111,31 @@ def test_packed_pair_words_and_wide_pairs_build_the_same_lists(n, w, h, deg, til
     for f in ("tile_offsets", "sorted_gauss", "stream_rec", "img", "final_T"):
         _same(getattr(a, f)[:a.num_pairs] if f in ("sorted_gauss", "stream_rec") else getattr(a, f),
               getattr(b, f)[:a.num_pairs] if f in ("sorted_gauss", "stream_rec") else getattr(b, f), f)
+
+
+def test_batched_front_with_a_view_that_sees_nothing():
+    """One of the views of a minibatch looks away from the cloud: its state reports nothing visible, the others are
+    unaffected, and render_views returns gradients equal to those of the views that see something."""
+    from gsplat_amd import rasterizer as R
+    from gsplat_amd.camera import Camera
+    from gsplat_amd.minibatch import render_views
+    from gsplat_amd.scenes import synthetic_scene
+    dev, params, views = _scene(20_000, 320, 200, 2, 3)
+    sc = synthetic_scene(20_000, 320, 200, 2, seed=0)
+    # ten thousand units to the side: the whole cloud falls outside the clip window of this camera
+    away = Camera(np.array([1.0e4, 0.0, 0.0]), np.array([1.0, 0.0, 0.0, 0.0]), sc.fx, sc.fy, 160, 100, 320, 200, device=dev)
+    blind = R.ViewSpec.from_camera(away, 2, 16)
+    mixed = [views[0], blind, views[1]]
+    states = R.forward_begin_views(*params, mixed)
+    for st in states:
+        R.forward_lists(st)
+    if states[1].num_visible != 0:
+        pytest.skip("the displaced camera still sees part of the synthetic cloud")
+    assert states[0].num_visible > 0 and states[2].num_visible > 0
+    cot = torch.rand(320, 200, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    _, g_mixed, s_mixed = render_views(params, mixed, lambda i, st: cot)
+    _, g_seen, s_seen = render_views(params, [views[0], views[1]], lambda i, st: cot)
+    torch.cuda.synchronize()
+    assert len(s_mixed) == len(s_seen) == 2
+    for a, b in zip(list(g_mixed) + list(s_mixed), list(g_seen) + list(s_seen)):
+        _same(a, b, "gradients with and without the blind view")
