@@ -8,11 +8,11 @@
 // by ceil(L/16)^2 such waves, all streaming the tile's list.  The list is a contiguous stream of
 // 64-byte splat records in depth order; the record address is wave-uniform, so a record is fetched
 // with ONE scalar load into 16 SGPRs and broadcast to the vector ALU for free - no LDS staging,
-// no barriers, waves are fully independent.  The loops are bound by the vector ALU and by the
-// scalar unit, which the four SIMDs of a CU share: every scalar instruction of the per-entry
-// bookkeeping (addresses, waits, flag tests, branches) costs about four cycles of a busy SIMD,
-// so the loops are written to need as few of them as possible - 32-bit running byte offsets, one
-// load per record, hint flags and the gradient slot inside the record.
+// no barriers, waves are fully independent.  The loops are bound by the ISSUE of vector instructions
+// (SQ counters: the vector ALU is busy 80-90 % of a launch at 4.3-4.4 cycles per instruction, the scalar
+// unit a quarter of it), so what counts is the number of vector instructions per list entry: packed
+// pairs, wave-uniform values kept in scalar registers, no register copies at the loop's back edge
+// (see the loop structure below), no reduction where a running sum does (bwd_sweep).
 //
 // Semantics follow the reference exactly (GaussianRenderer.py:100-112, Utils/Probability.py):
 // integer pixel coordinates, alpha = clamp(opacity*G, 0.01, 0.99) for EVERY list entry, the

@@ -99,14 +99,14 @@ def reserve_streams(device=None):
 
 def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Optional[Callable], grads=None,
                  accumulate: bool = False, overlap: bool = True, lookahead: int = 2, g_colors=None, batch_front: bool = True):
-    """Forward + backward of the views of one rank against the same parameters, software-pipelined over
-    two HIP streams.
+    """Forward + backward of the views of one rank against the same parameters.
 
-    A view's work falls into a front part that is bound by memory bandwidth and by the latency of many
-    small launches (stage 1, depth sort, pair emission, tile sort, record stream) and a back part that
-    is bound by the vector ALU (compositing forward and backward, record sums).  The front part of view
-    i+1.. runs on a side stream while the current stream composites view i; ``lookahead`` views are
-    begun before the first one's counters are waited for, so the host never stalls the GPU.
+    Stage 1 and the depth order of ALL views are one set of launches (``batch_front``: the parameters are read
+    once, the sort kernels take the views as a batch).  The rest of a view's front part (pair emission, tile sort,
+    record stream: bound by memory bandwidth) runs on a side stream beside the compositing of the view before it
+    (forward, backward, record sums: bound by vector instruction issue).  Without ``batch_front`` the whole front
+    part of view i+1.. runs on the side stream, ``lookahead`` views begun before the first one's counters are
+    waited for, so that the host never stalls the GPU.
 
     ``params``: coords, scale_raw, rot_raw, opac_raw, sh.  ``views``: ``ViewSpec``s.
     ``cotangent(i, state)`` returns dL/dimg of view ``i`` (called with the current stream current, after
