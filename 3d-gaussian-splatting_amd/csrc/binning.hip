@@ -120,11 +120,15 @@ __device__ inline bool tile_all_clamped_low(float gx, float gy, float A, float B
     } else {
         fmin = 3.0e38f;
         const float ex[2] = {dx0, dx1}, ey[2] = {dy0, dy1};
+        // (hardware reciprocals, one ulp: the minimiser along an edge only has to be close - the form is
+        // evaluated AT it, and the slack below covers the rest; four correctly rounded divisions per test cost
+        // more vector instructions than everything else in this kernel)
+        const float over_d = -bh * __builtin_amdgcn_rcpf(d), over_a = -bh * __builtin_amdgcn_rcpf(a);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            float t = fminf(fmaxf(-bh * ex[k] / d, dy0), dy1);        // edge dx = ex[k]
+            float t = fminf(fmaxf(ex[k] * over_d, dy0), dy1);         // edge dx = ex[k]
             fmin = fminf(fmin, a * ex[k] * ex[k] + 2.0f * bh * ex[k] * t + d * t * t);
-            t = fminf(fmaxf(-bh * ey[k] / a, dx0), dx1);              // edge dy = ey[k]
+            t = fminf(fmaxf(ey[k] * over_a, dx0), dx1);               // edge dy = ey[k]
             fmin = fminf(fmin, a * t * t + 2.0f * bh * t * ey[k] + d * ey[k] * ey[k]);
         }
     }

@@ -45,6 +45,7 @@ struct WaveGeom {
     uint32_t begin, end; // list range (wave-uniform)
     uint32_t total;      // records in the whole stream
     uint32_t flag_shift; // position of this block's two hint bits in a record's flags
+    uint32_t turn;       // rank of the tile in the order the grid takes the tiles
 };
 
 // tile_order (may be null): the tiles in the order in which the waves of the grid take them - longest
@@ -64,6 +65,7 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
     const int xi = (int)(tile / (unsigned)v.nbh), yi = (int)(tile - (unsigned)xi * v.nbh);
     const int lane = threadIdx.x & 63;
     w.tile = (int)tile;
+    w.turn = turn;
     w.flag_shift = 2u * (sub & 15u);
     w.x = xi * v.L + sxi * 16 + (lane >> 2);
     w.y0 = yi * v.L + syi * 16 + (lane & 3);
@@ -79,7 +81,17 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
 // The compositing waves are bound by instruction issue.  When memory-bound kernels of another view
 // run beside them on a second stream (minibatch.render_views), the SIMD's issue arbiter should serve
 // these waves first and give the others the cycles they leave.
-__device__ inline void raise_wave_priority() { __builtin_amdgcn_s_setprio(3); }
+__device__ inline void raise_wave_priority(const WaveGeom &w, int T)
+{
+    // and among themselves: the longer the list, the higher the priority (lists are taken longest first, `turn`
+    // is the list's rank).  The waves with the longest lists are the critical path of a launch; served first,
+    // they finish early and the SIMD's issue slots go to the shorter ones instead of running out at the end.
+    const unsigned quarter = (unsigned)w.turn * 4u / (unsigned)max(T, 1);
+    if (quarter == 0u) __builtin_amdgcn_s_setprio(3);
+    else if (quarter == 1u) __builtin_amdgcn_s_setprio(2);
+    else if (quarter == 2u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
 {
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
-    raise_wave_priority();
+    raise_wave_priority(w, v.T);
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], cr[2], cg[2], cb[2];   // pixel rows (y0, y0+4): top half, (y0+8, y0+12): bottom half
 #pragma unroll
@@ -617,7 +629,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
     if (w.begin >= w.end) return;   // (the same for every wave of a tile group)
-    raise_wave_priority();
+    raise_wave_priority(w, v.T);
     GroupSlot gs = {nullptr, nullptr, 0u, 1u, 0u, 0u, 0u, 1u};
     if (MODE == kTileGroup) {
         __shared__ float group_parts[2 * kGroupChunk * kGroupMaxWaves * GSR_PAIRGRAD_FLOATS];   // 12 KiB
