@@ -409,6 +409,14 @@ __device__ inline void group_flush(GroupSlot &gs, uint32_t count, float *pairgra
     gs.entry = 0;
 }
 
+// a * b with 0 * x = 0 for every x, NaN and infinities included (v_mul_legacy_f32)
+__device__ inline float mul_zero_wins(float a, float b)
+{
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Full record, floats: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2, dL/d(opacity),
 // dL/d(red), dL/d(green), then four partial sums of dL/d(blue).
 // Returns, on every writer lane of a full record, the float that lane stores (before any rescaling).
@@ -552,7 +560,9 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             } else {
                 half_low(0, R, k, red, true, false);
                 half_low(1, R, k, red, false, false);
-                put_record<MODE>(pairgrad, rec_off, lanes.full_off, U * low_gain, kFullWriters, gs);   // zeros in floats 0..5
+                // (legacy multiply: 0 * x = 0 whatever x is, so the six geometric floats of the record are zeros even when a
+                // NaN of a diverged model has reached U on the lanes that do not hold a colour sum)
+                put_record<MODE>(pairgrad, rec_off, lanes.full_off, mul_zero_wins(U, low_gain), kFullWriters, gs);
                 U = fmaf(U, low_gain, U);
             }
             return;
