@@ -26,7 +26,8 @@ SYMBOLS = (
     "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_sort_pairs64", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
     "gsr_exclusive_scan_static",
     "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_offsets_views_workspace_bytes", "gsr_bin_offsets_views",
-    "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order",
+    "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order", "gsr_bin_lists_views_supported",
+    "gsr_bin_lists_views_layout", "gsr_bin_lists_views_workspace_bytes", "gsr_bin_lists_views",
     "gsr_composite_fwd", "gsr_composite_bwd", "gsr_pairgrad_parts",
     "gsr_loss_workspace_bytes", "gsr_loss_fwd_bwd",
     "gsr_adam_step", "gsr_knn_dist2",
@@ -106,6 +107,13 @@ def load():
     lib.gsr_bin_offsets_views.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_bin_lists.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_tile_order.argtypes = [C.POINTER(GsrView), vp, vp, vp]
+    u32p = C.POINTER(C.c_uint32)
+    lib.gsr_bin_lists_views_supported.argtypes = [C.POINTER(GsrView), C.c_uint32, u32p]
+    lib.gsr_bin_lists_views_layout.restype = C.c_uint64
+    lib.gsr_bin_lists_views_layout.argtypes = [C.c_uint32, u32p, u32p]
+    lib.gsr_bin_lists_views_workspace_bytes.restype = C.c_size_t
+    lib.gsr_bin_lists_views_workspace_bytes.argtypes = [C.c_uint32, u32p]
+    lib.gsr_bin_lists_views.argtypes = [C.POINTER(GsrView), C.c_uint32] + [vp] * 6 + [u32p] + [vp] * 5 + [C.c_size_t, vp]
     lib.gsr_composite_fwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, vp]
     lib.gsr_composite_bwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, C.c_uint32, vp, vp]
     lib.gsr_loss_workspace_bytes.restype = C.c_size_t

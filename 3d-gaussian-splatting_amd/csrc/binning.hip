@@ -19,6 +19,21 @@ __global__ void iota_kernel(uint32_t *__restrict__ out, uint32_t n)
     if (i < n) out[(size_t)blockIdx.y * n + i] = i;
 }
 
+// The lists of several views of the same Gaussians built by one set of launches (blockIdx.y = view): view y has
+// n[y] pairs from element base[y] (a multiple of 4096) of the per-pair arrays; the per-Gaussian inputs of view y
+// start y * N elements (rows) into their arrays, its tile offsets y * (T + 1), its tile order y * T.  count == 0: one view.
+struct ListSegs {
+    uint32_t count;
+    uint32_t n[GSR_MAX_SEGS], base[GSR_MAX_SEGS];
+};
+__device__ inline uint32_t seg_pick(const uint32_t (&a)[GSR_MAX_SEGS], uint32_t y)
+{
+    uint32_t r = a[0];
+#pragma unroll
+    for (uint32_t k = 1; k < GSR_MAX_SEGS; ++k) r = y == k ? a[k] : r;
+    return r;
+}
+
 // A (tile, Gaussian, slot) triple in one 64-bit word: slot in the low `slot` bits, the Gaussian above it, the
 // tile id above that.  The tile sort then moves 8 bytes per pair and pass instead of a 4-byte key and an
 // 8-byte value.  Used whenever the three fields fit 64 bits (gsr_bin_lists decides).
@@ -44,8 +59,15 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
                                                          const uint32_t *__restrict__ ntiles,
                                                          uint32_t *__restrict__ tile_key,
                                                          uint64_t *__restrict__ owner_slot, uint32_t num_pairs,
-                                                         PairBits bits)
+                                                         PairBits bits, ListSegs segs)
 {
+    if (segs.count) {
+        const size_t at = (size_t)blockIdx.y * (size_t)v.n;
+        order += at; slot_base += at; bbox += 4 * at; ntiles += at;
+        if (slot_seq) slot_seq += at + blockIdx.y;          // (n + 1 entries per view)
+        num_pairs = seg_pick(segs.n, blockIdx.y);
+        owner_slot += seg_pick(segs.base, blockIdx.y);
+    }
     const int s = blockIdx.x * blockDim.x + threadIdx.x;   // position in depth order
     uint32_t g = 0, sb = 0xFFFFFFFFu, nt = 0;
     int x0 = 0, y0 = 0, ny = 1;
@@ -145,8 +167,20 @@ __device__ inline bool tile_all_clamped_low(float gx, float gy, float A, float B
 __global__ __launch_bounds__(256) void finalize_lists_kernel(
     ViewK v, const uint32_t *__restrict__ sorted_tile, const uint64_t *__restrict__ sorted_owner_slot,
     const float *__restrict__ rec, uint32_t num_pairs, uint32_t T, uint32_t *__restrict__ tile_offsets,
-    uint32_t *__restrict__ pair_slot, uint32_t *__restrict__ sorted_gauss, float *__restrict__ stream_rec, PairBits bits)
+    uint32_t *__restrict__ pair_slot, uint32_t *__restrict__ sorted_gauss, float *__restrict__ stream_rec, PairBits bits,
+    ListSegs segs)
 {
+    if (segs.count) {
+        num_pairs = seg_pick(segs.n, blockIdx.y);
+        const uint32_t base = seg_pick(segs.base, blockIdx.y);
+        if (blockIdx.x * blockDim.x >= num_pairs) return;
+        sorted_owner_slot += base;
+        if (pair_slot) pair_slot += base;
+        sorted_gauss += base;
+        stream_rec += (size_t)base * GSR_STREAM_DWORDS;
+        rec += (size_t)blockIdx.y * (size_t)v.n * GSR_REC_FLOATS;
+        tile_offsets += (size_t)blockIdx.y * (T + 1u);
+    }
     // (sorted_tile == null: sorted_owner_slot holds packed words, see pack_pair)
     // The 64-byte records of a wave's 64 pairs are one contiguous 4 KiB piece of the stream: they go
     // through LDS so that every store instruction writes 1 KiB of consecutive addresses.
@@ -248,6 +282,8 @@ __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(uint32_t T, c
 {
     __shared__ uint32_t s_count[kOrderBuckets];
     __shared__ uint32_t s_max[kOrderThreads / GSR_WAVE];
+    tile_offsets += (size_t)blockIdx.y * (T + 1u);   // (blockIdx.y: one of several views, one after the other)
+    tile_order += (size_t)blockIdx.y * T;
     const uint32_t t = threadIdx.x;
     uint32_t mx = 0;
     for (uint32_t i = t; i < T; i += kOrderThreads) mx = max(mx, tile_offsets[i + 1] - tile_offsets[i]);
@@ -435,22 +471,129 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, c
     bool in_first;
     if (packed) {
         hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, order, slot_seq, slot_base,
-                           bbox, ntiles, (uint32_t *)nullptr, owner_slot, num_pairs, bits);
+                           bbox, ntiles, (uint32_t *)nullptr, owner_slot, num_pairs, bits, ListSegs{});
         if (int e = gsr_sort_words64(owner_slot, sorted_owner_slot, num_pairs, bits.slot + bits.gauss,
                                      bits.slot + bits.gauss + tile_bits, sort_ws, sort_bytes, stream, &in_first))
             return e;
         hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
                            (const uint32_t *)nullptr, in_first ? owner_slot : sorted_owner_slot, rec, num_pairs, (uint32_t)v.T,
-                           tile_offsets, pair_slot, sorted_gauss, stream_rec, bits);
+                           tile_offsets, pair_slot, sorted_gauss, stream_rec, bits, ListSegs{});
         return gsr_check_launch("bin_lists");
     }
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256)), dim3(256), 0, st, v, order, slot_seq, slot_base,
-                       bbox, ntiles, tile_key, owner_slot, num_pairs, bits);
+                       bbox, ntiles, tile_key, owner_slot, num_pairs, bits, ListSegs{});
     if (int e = gsr_sort_pingpong64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0, tile_bits, sort_ws,
                                     sort_bytes, stream, &in_first))
         return e;
     hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
                        in_first ? tile_key : sorted_tile, in_first ? owner_slot : sorted_owner_slot, rec, num_pairs,
-                       (uint32_t)v.T, tile_offsets, pair_slot, sorted_gauss, stream_rec, bits);
+                       (uint32_t)v.T, tile_offsets, pair_slot, sorted_gauss, stream_rec, bits, ListSegs{});
     return gsr_check_launch("bin_lists");
 }
+
+// ---- the lists of several views at once ------------------------------------------------------------------------
+static bool lists_views_fit(const ViewK &v, uint32_t most_pairs, PairBits *bits, int *tile_bits)
+{
+    bits->slot = bits_for(most_pairs);
+    bits->gauss = bits_for((uint32_t)v.n);
+    *tile_bits = bits_for((uint32_t)v.T);
+    return bits->slot + bits->gauss + *tile_bits <= 64 && bits->gauss < 32 && bits->slot < 32 && !gsr_force_wide_pairs();
+}
+
+static int lists_views_check(const gsr_view *views_host, uint32_t num_views, const uint32_t *num_pairs, ViewK *v, uint32_t *most)
+{
+    if (!views_host || !num_pairs || num_views == 0 || num_views > GSR_MAX_SEGS) {
+        gsr_set_error("gsr_bin_lists_views: %u views (1..%d expected)", num_views, GSR_MAX_SEGS);
+        return GSR_ERR_ARG;
+    }
+    if (int e = gsr_make_view(&views_host[0], v)) return e;
+    *most = 0;
+    for (uint32_t k = 0; k < num_views; ++k) {
+        ViewK o;
+        if (int e = gsr_make_view(&views_host[k], &o)) return e;
+        if (o.n != v->n || o.W != v->W || o.H != v->H || o.L != v->L) {
+            gsr_set_error("gsr_bin_lists_views: view %u differs from view 0 in the number of Gaussians, the image size or the tile edge", k);
+            return GSR_ERR_ARG;
+        }
+        if ((unsigned long long)num_pairs[k] * GSR_STREAM_DWORDS * 4ull >= (1ull << 32)) {
+            gsr_set_error("gsr_bin_lists_views: %u pairs in view %u: the record stream would reach 4 GiB", num_pairs[k], k);
+            return GSR_ERR_ARG;
+        }
+        *most = num_pairs[k] > *most ? num_pairs[k] : *most;
+    }
+    return GSR_OK;
+}
+
+extern "C" int gsr_bin_lists_views_supported(const gsr_view *views_host, uint32_t num_views, const uint32_t *num_pairs)
+{
+    ViewK v;
+    uint32_t most;
+    if (lists_views_check(views_host, num_views, num_pairs, &v, &most)) return 0;
+    PairBits bits;
+    int tile_bits;
+    return lists_views_fit(v, most, &bits, &tile_bits) ? 1 : 0;
+}
+
+// Element offset of every view's pairs in the concatenated per-pair arrays (multiples of 4096) and their total length.
+extern "C" uint64_t gsr_bin_lists_views_layout(uint32_t num_views, const uint32_t *num_pairs, uint32_t *pair_base)
+{
+    uint64_t at = 0;
+    for (uint32_t k = 0; k < num_views; ++k) {
+        if (pair_base) pair_base[k] = (uint32_t)at;
+        at += (uint64_t)gsr_div_up(num_pairs[k], 4096u) * 4096u;
+    }
+    return at ? at : 4096u;
+}
+
+extern "C" size_t gsr_bin_lists_views_workspace_bytes(uint32_t num_views, const uint32_t *num_pairs)
+{
+    const uint64_t total = gsr_bin_lists_views_layout(num_views, num_pairs, nullptr);
+    return 2 * align256((size_t)total * sizeof(uint64_t)) + gsr_sort_words64_segs_bytes(num_pairs, num_views);
+}
+
+extern "C" int gsr_bin_lists_views(const gsr_view *views_host, uint32_t num_views, const uint32_t *order, const uint32_t *slot_base,
+                                   const uint32_t *slot_seq, const int32_t *bbox, const uint32_t *ntiles, const float *rec,
+                                   const uint32_t *num_pairs, uint32_t *tile_offsets, uint32_t *tile_order, uint32_t *sorted_gauss,
+                                   float *stream_rec, void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    ViewK v;
+    uint32_t most;
+    if (int e = lists_views_check(views_host, num_views, num_pairs, &v, &most)) return e;
+    PairBits bits;
+    int tile_bits;
+    if (!lists_views_fit(v, most, &bits, &tile_bits)) {
+        gsr_set_error("gsr_bin_lists_views: tile, Gaussian and slot do not fit one 64-bit word (see gsr_bin_lists_views_supported)");
+        return GSR_ERR_ARG;
+    }
+    if (!order || !slot_base || !bbox || !ntiles || !rec || !tile_offsets || !sorted_gauss || !stream_rec || !workspace ||
+        workspace_bytes < gsr_bin_lists_views_workspace_bytes(num_views, num_pairs)) {
+        gsr_set_error("gsr_bin_lists_views: null pointer or workspace too small");
+        return GSR_ERR_ARG;
+    }
+    ListSegs segs = {};
+    segs.count = num_views;
+    uint32_t base[GSR_MAX_SEGS];
+    const uint64_t total = gsr_bin_lists_views_layout(num_views, num_pairs, base);
+    if (total >= (1ull << 32)) { gsr_set_error("gsr_bin_lists_views: too many pairs in all"); return GSR_ERR_ARG; }
+    for (uint32_t k = 0; k < num_views; ++k) { segs.n[k] = num_pairs[k]; segs.base[k] = base[k]; }
+    // views without pairs have all-zero tile offsets; the others are written in full by finalize_lists
+    (void)hipMemsetAsync(tile_offsets, 0, (size_t)num_views * (size_t)(v.T + 1) * sizeof(uint32_t), st);
+    if (most == 0) return GSR_OK;
+    const size_t arr = align256((size_t)total * sizeof(uint64_t));
+    uint64_t *words = (uint64_t *)workspace, *words_b = (uint64_t *)((char *)workspace + arr);
+    void *sort_ws = (char *)workspace + 2 * arr;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(v.n, 256), num_views), dim3(256), 0, st, v, order, slot_seq, slot_base,
+                       bbox, ntiles, (uint32_t *)nullptr, words, 0u, bits, segs);
+    bool in_first;
+    if (int e = gsr_sort_words64_segs(words, words_b, segs.n, segs.base, num_views, bits.slot + bits.gauss,
+                                      bits.slot + bits.gauss + tile_bits, sort_ws, workspace_bytes - 2 * arr, stream, &in_first))
+        return e;
+    hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(most, 256), num_views), dim3(256), 0, st, v, (const uint32_t *)nullptr,
+                       in_first ? words : words_b, rec, 0u, (uint32_t)v.T, tile_offsets, (uint32_t *)nullptr, sorted_gauss, stream_rec,
+                       bits, segs);
+    if (tile_order)
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1, num_views), dim3(kOrderThreads), 0, st, (uint32_t)v.T, tile_offsets, tile_order);
+    return gsr_check_launch("bin_lists_views");
+}
+

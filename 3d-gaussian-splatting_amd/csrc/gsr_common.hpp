@@ -29,6 +29,11 @@ int gsr_sort_pingpong64(uint32_t *keys_a, uint64_t *vals_a, uint32_t *keys_b, ui
                         int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
 int gsr_sort_words64(uint64_t *words_a, uint64_t *words_b, uint32_t n, int begin_bit, int end_bit, void *workspace,
                      size_t workspace_bytes, void *stream, bool *result_in_first);   // 64-bit words by their own bits
+#define GSR_MAX_SEGS 8
+size_t gsr_sort_words64_segs_bytes(const uint32_t *n, uint32_t count);
+int gsr_sort_words64_segs(uint64_t *words_a, uint64_t *words_b, const uint32_t *n, const uint32_t *base, uint32_t count,
+                          int begin_bit, int end_bit, void *workspace, size_t workspace_bytes, void *stream,
+                          bool *result_in_first);   // sequences of different lengths, each from a multiple of 4096
 int gsr_sort_pingpong32_batch(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, uint32_t nseq,
                               int begin_bit, int end_bit, void *workspace, size_t workspace_bytes, void *stream,
                               bool *result_in_first);   // nseq sequences of n pairs, one after the other

@@ -166,19 +166,44 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
 
 // ---- radix sort -------------------------------------------------------------------------
 
+// Sequences of DIFFERENT lengths sorted by one set of launches (blockIdx.y = sequence): sequence y has n[y] items
+// from element base[y] of the buffers (a multiple of the 4096 items of a sort block), nb[y] sort blocks, and its
+// per-block digit counts from word hbase[y] of the histogram buffer.  count == 0: the sequences all have the
+// kernel's n (or there is one).
+struct SortSegs {
+    uint32_t count;
+    uint32_t n[GSR_MAX_SEGS], base[GSR_MAX_SEGS], nb[GSR_MAX_SEGS], hbase[GSR_MAX_SEGS];
+};
+// a[y] without a dynamically indexed copy of the kernel arguments in scratch memory
+__device__ inline uint32_t seg_pick(const uint32_t (&a)[GSR_MAX_SEGS], uint32_t y)
+{
+    uint32_t r = a[0];
+#pragma unroll
+    for (uint32_t k = 1; k < GSR_MAX_SEGS; ++k) r = y == k ? a[k] : r;
+    return r;
+}
+
 // hist[digit * nb + block] = number of keys of the block's tile with that digit.
 // K = uint32_t: the keys of a (key, value) sort; K = uint64_t: 64-bit words sorted by some of their own bits.
 template <typename K>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const K *__restrict__ keys, uint32_t n,
                                                                   int shift, uint32_t mask, uint32_t nb,
-                                                                  uint32_t *__restrict__ hist)
+                                                                  uint32_t *__restrict__ hist, SortSegs segs)
 {
     __shared__ uint32_t h[RADIX_SIZE];
+    if (segs.count) {
+        n = seg_pick(segs.n, blockIdx.y);
+        nb = seg_pick(segs.nb, blockIdx.y);
+        if (blockIdx.x >= nb) return;
+        keys += seg_pick(segs.base, blockIdx.y);
+        hist += seg_pick(segs.hbase, blockIdx.y);
+    } else {
+        // (sequence blockIdx.y of a batch of equally long ones: y * n keys and y * 256 * nb counts further on)
+        keys += (size_t)blockIdx.y * n;
+        hist += (size_t)blockIdx.y * RADIX_SIZE * nb;
+    }
     h[threadIdx.x] = 0;
     __syncthreads();
-    // (sequence blockIdx.y of a batch of equally long ones: y * n keys and y * 256 * nb counts further on)
-    keys += (size_t)blockIdx.y * n;
-    hist += (size_t)blockIdx.y * RADIX_SIZE * nb;
     const uint32_t base = blockIdx.x * SORT_TILE;
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
@@ -193,10 +218,15 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const K *__res
 // scans row d of hist (the nb counts of digit d, one per sort block) in place and writes the row total
 // to digit_total[d].  The scatter kernel adds the digit's own base (a scan of the 256 totals).
 __global__ __launch_bounds__(256) void radix_rows_kernel(uint32_t *__restrict__ hist, uint32_t nb,
-                                                         uint32_t *__restrict__ digit_total)
+                                                         uint32_t *__restrict__ digit_total, SortSegs segs)
 {
     __shared__ uint32_t lds[256 / 64 + 1];
-    hist += (size_t)blockIdx.y * RADIX_SIZE * nb;
+    if (segs.count) {
+        nb = seg_pick(segs.nb, blockIdx.y);
+        hist += seg_pick(segs.hbase, blockIdx.y);
+    } else {
+        hist += (size_t)blockIdx.y * RADIX_SIZE * nb;
+    }
     digit_total += (size_t)blockIdx.y * RADIX_SIZE;
     uint32_t *row = hist + (size_t)blockIdx.x * nb;
     uint32_t carry = 0;
@@ -227,7 +257,7 @@ template <typename V, bool STAGED, bool WORDS = false>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     V *__restrict__ vals_out, uint32_t n, int shift, uint32_t mask, uint32_t nb,
-    const uint32_t *__restrict__ hist_rows, const uint32_t *__restrict__ digit_total)
+    const uint32_t *__restrict__ hist_rows, const uint32_t *__restrict__ digit_total, SortSegs segs)
 {
     __shared__ uint32_t cnt[SORT_WAVES][RADIX_SIZE];   // per-wave digit counts, then per-wave local offsets
     __shared__ uint32_t lstart[RADIX_SIZE];            // first local position of a digit inside the tile
@@ -236,11 +266,21 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     __shared__ V stage[STAGED ? SORT_TILE : 1];        // keys (as words), then values, in digit order
     uint32_t *stage_keys = reinterpret_cast<uint32_t *>(stage);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (!WORDS) { keys_in += (size_t)blockIdx.y * n; keys_out += (size_t)blockIdx.y * n; }
-    vals_in += (size_t)blockIdx.y * n; vals_out += (size_t)blockIdx.y * n;
+    if (segs.count) {
+        n = seg_pick(segs.n, blockIdx.y);
+        nb = seg_pick(segs.nb, blockIdx.y);
+        if (blockIdx.x >= nb) return;
+        const uint32_t base = seg_pick(segs.base, blockIdx.y);
+        if (!WORDS) { keys_in += base; keys_out += base; }
+        vals_in += base; vals_out += base;
+        hist_rows += seg_pick(segs.hbase, blockIdx.y);
+    } else {
+        if (!WORDS) { keys_in += (size_t)blockIdx.y * n; keys_out += (size_t)blockIdx.y * n; }
+        vals_in += (size_t)blockIdx.y * n; vals_out += (size_t)blockIdx.y * n;
+        hist_rows += (size_t)blockIdx.y * RADIX_SIZE * nb;
+    }
     const int word_shift = shift;   // WORDS: position of the digit inside the 64-bit word
     if (WORDS) shift = 0;
-    hist_rows += (size_t)blockIdx.y * RADIX_SIZE * nb;
     digit_total += (size_t)blockIdx.y * RADIX_SIZE;
     // first position of digit d in the output: exclusive scan of the 256 digit totals
     uint32_t digit_base;
@@ -352,6 +392,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 }  // namespace
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static const SortSegs no_segs = {};
 
 extern "C" size_t gsr_scan_workspace_bytes(uint32_t n)
 {
@@ -494,14 +535,14 @@ static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_
     for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
         const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
         const uint32_t mask = (1u << nbits) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel<uint32_t>, dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist);
-        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE, nseq), dim3(256), 0, st, hist, nb, digit_total);
+        hipLaunchKernelGGL(radix_hist_kernel<uint32_t>, dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist, no_segs);
+        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE, nseq), dim3(256), 0, st, hist, nb, digit_total, no_segs);
         if (sizeof(V) > 4 || staged32)
             hipLaunchKernelGGL((radix_scatter_kernel<V, true>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, vi, ko,
-                               vo, n, bit, mask, nb, hist, digit_total);
+                               vo, n, bit, mask, nb, hist, digit_total, no_segs);
         else
             hipLaunchKernelGGL((radix_scatter_kernel<V, false>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, vi, ko,
-                               vo, n, bit, mask, nb, hist, digit_total);
+                               vo, n, bit, mask, nb, hist, digit_total, no_segs);
         uint32_t *t = ki; ki = ko; ko = t;
         V *tv = vi; vi = vo; vo = tv;
         *result_in_first = !*result_in_first;
@@ -532,14 +573,66 @@ int gsr_sort_words64(uint64_t *words_a, uint64_t *words_b, uint32_t n, int begin
     for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
         const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
         const uint32_t mask = (1u << nbits) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel<uint64_t>, dim3(nb), dim3(SORT_THREADS), 0, st, wi, n, bit, mask, nb, hist);
-        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE), dim3(256), 0, st, hist, nb, digit_total);
+        hipLaunchKernelGGL(radix_hist_kernel<uint64_t>, dim3(nb), dim3(SORT_THREADS), 0, st, wi, n, bit, mask, nb, hist, no_segs);
+        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE), dim3(256), 0, st, hist, nb, digit_total, no_segs);
         hipLaunchKernelGGL((radix_scatter_kernel<uint64_t, true, true>), dim3(nb), dim3(SORT_THREADS), 0, st,
-                           (const uint32_t *)nullptr, wi, (uint32_t *)nullptr, wo, n, bit, mask, nb, hist, digit_total);
+                           (const uint32_t *)nullptr, wi, (uint32_t *)nullptr, wo, n, bit, mask, nb, hist, digit_total, no_segs);
         uint64_t *t = wi; wi = wo; wo = t;
         *result_in_first = !*result_in_first;
     }
     return gsr_check_launch("sort_words64");
+}
+
+// gsr_sort_words64 for `count` sequences of different lengths with one set of launches: sequence y has n[y] words
+// from element base[y] (a multiple of 4096) of both buffers.  The workspace holds gsr_sort_words64_segs_bytes().
+size_t gsr_sort_words64_segs_bytes(const uint32_t *n, uint32_t count)
+{
+    size_t blocks = 0;
+    for (uint32_t y = 0; y < count; ++y) blocks += gsr_div_up(n[y], SORT_TILE);
+    return align256(blocks * RADIX_SIZE * sizeof(uint32_t)) + align256((size_t)count * RADIX_SIZE * sizeof(uint32_t));
+}
+
+int gsr_sort_words64_segs(uint64_t *words_a, uint64_t *words_b, const uint32_t *n, const uint32_t *base, uint32_t count,
+                          int begin_bit, int end_bit, void *workspace, size_t workspace_bytes, void *stream,
+                          bool *result_in_first)
+{
+    hipStream_t st = (hipStream_t)stream;
+    *result_in_first = true;
+    if (count == 0 || count > GSR_MAX_SEGS || begin_bit < 0 || end_bit > 64 || begin_bit > end_bit) {
+        gsr_set_error("gsr_sort_words64_segs: bad sequence count or bit range");
+        return GSR_ERR_ARG;
+    }
+    if (!workspace || workspace_bytes < gsr_sort_words64_segs_bytes(n, count) || !words_a || !words_b) {
+        gsr_set_error("gsr_sort_words64_segs: null pointer or workspace too small");
+        return GSR_ERR_ARG;
+    }
+    SortSegs segs = {};
+    segs.count = count;
+    uint32_t blocks = 0, most = 0;
+    for (uint32_t y = 0; y < count; ++y) {
+        if (base[y] % SORT_TILE) { gsr_set_error("gsr_sort_words64_segs: a sequence does not start at a multiple of %d", SORT_TILE); return GSR_ERR_ARG; }
+        segs.n[y] = n[y];
+        segs.base[y] = base[y];
+        segs.nb[y] = gsr_div_up(n[y], SORT_TILE);
+        segs.hbase[y] = blocks * RADIX_SIZE;
+        blocks += segs.nb[y];
+        most = segs.nb[y] > most ? segs.nb[y] : most;
+    }
+    if (most == 0) return GSR_OK;
+    uint32_t *hist = (uint32_t *)workspace;
+    uint32_t *digit_total = (uint32_t *)((char *)workspace + align256((size_t)blocks * RADIX_SIZE * sizeof(uint32_t)));
+    uint64_t *wi = words_a, *wo = words_b;
+    for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
+        const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
+        const uint32_t mask = (1u << nbits) - 1u;
+        hipLaunchKernelGGL(radix_hist_kernel<uint64_t>, dim3(most, count), dim3(SORT_THREADS), 0, st, wi, 0u, bit, mask, 0u, hist, segs);
+        hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE, count), dim3(256), 0, st, hist, 0u, digit_total, segs);
+        hipLaunchKernelGGL((radix_scatter_kernel<uint64_t, true, true>), dim3(most, count), dim3(SORT_THREADS), 0, st,
+                           (const uint32_t *)nullptr, wi, (uint32_t *)nullptr, wo, 0u, bit, mask, 0u, hist, digit_total, segs);
+        uint64_t *t = wi; wi = wo; wo = t;
+        *result_in_first = !*result_in_first;
+    }
+    return gsr_check_launch("sort_words64_segs");
 }
 
 // library-internal entry points (binning.hip): sort without the final copy

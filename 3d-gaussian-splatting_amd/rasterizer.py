@@ -258,22 +258,18 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views) -> list
 def forward_lists(st: RenderState) -> RenderState:
     """Waits for the view's counters (the one synchronisation of a render), sizes the per-pair
     buffers and builds the per-tile lists, the record stream and the tile order."""
+    if st._ready is not None:
+        read_counters(st)
+    return _lists_of(st)
+
+
+def _lists_of(st: RenderState) -> RenderState:
     lib = _lib.load()
     view, cv = st.view, st.cview
     dev = st.mask_u8.device
     stream = _stream(dev)
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    st._ready.synchronize()
-    host = st._host
-    st.num_visible, st.num_pairs, err = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2])
-    if host._base is None:
-        _pinned_pool.append(host)          # (a row of the buffer that several views share is not recycled)
-    st._host = st._counters = st._ready = None
-    if err & 1:
-        raise SingularCovarianceError("singular 2-D covariance in a Gaussian that lands in a tile")
-    if err & 2:
-        raise RuntimeError("the view has more than 2^32 - 1 (tile, Gaussian) pairs: the per-tile lists cannot be indexed")
     if st.num_visible == 0:
         return st
     T = ((view.width + view.tile_length - 1) // view.tile_length) * ((view.height + view.tile_length - 1) // view.tile_length)
@@ -291,6 +287,79 @@ def forward_lists(st: RenderState) -> RenderState:
         st.tile_order = torch.empty(T, **i32)
         _call("gsr_tile_order", lib.gsr_tile_order, cv, _ptr(st.tile_offsets), _ptr(st.tile_order), stream)
     return st
+
+
+def read_counters(st: RenderState):
+    """Waits for the view's counters and checks the error word (the one synchronisation of a render); does nothing
+    when they were read before."""
+    if st._ready is None:
+        return
+    st._ready.synchronize()
+    host = st._host
+    st.num_visible, st.num_pairs, err = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2])
+    if host._base is None:
+        _pinned_pool.append(host)          # (a row of the buffer that several views share is not recycled)
+    st._host = st._counters = st._ready = None
+    if err & 1:
+        raise SingularCovarianceError("singular 2-D covariance in a Gaussian that lands in a tile")
+    if err & 2:
+        raise RuntimeError("the view has more than 2^32 - 1 (tile, Gaussian) pairs: the per-tile lists cannot be indexed")
+
+
+def forward_lists_views(states) -> list:
+    """``forward_lists`` for the states ``forward_begin_views`` returned (views of one group of at most
+    ``_lib.MAX_VIEWS``, consecutive slices of the same arrays): pair emission, tile sort, record stream and tile order
+    of all of them with one set of launches.  Falls back to ``forward_lists`` view by view when the views do not
+    qualify (different sizes, or more tiles, Gaussians and pairs than one 64-bit word per pair holds)."""
+    import ctypes as C
+    states = list(states)
+    if not states:
+        return states
+    lib = _lib.load()
+    for st in states:
+        if st._ready is not None:
+            read_counters(st)
+    first = states[0]
+    nv, n = len(states), first.n
+    base_t = first.order._base
+    batched = (nv > 1 and nv <= _lib.MAX_VIEWS and base_t is not None and os.environ.get("GSR_TILE_ORDER", "length") != "id" and
+               all(st.order._base is base_t and st.order.storage_offset() == k * n for k, st in enumerate(states)))
+    pairs = (C.c_uint32 * nv)(*[st.num_pairs if st.num_visible else 0 for st in states])
+    cviews = (_lib.GsrView * nv)(*[st.cview for st in states])
+    if batched:
+        batched = bool(lib.gsr_bin_lists_views_supported(cviews, nv, pairs))
+    if not batched:
+        for st in states:
+            if st.tile_offsets is None:
+                _lists_of(st)
+        return states
+    dev = first.mask_u8.device
+    stream = _stream(dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    view = first.view
+    T = ((view.width + view.tile_length - 1) // view.tile_length) * ((view.height + view.tile_length - 1) // view.tile_length)
+    bases = (C.c_uint32 * nv)()
+    total = int(lib.gsr_bin_lists_views_layout(nv, pairs, bases))
+    tile_offsets = torch.empty(nv, T + 1, **i32)
+    tile_order = torch.empty(nv, T, **i32)
+    sorted_gauss = torch.empty(total, **i32)
+    stream_rec = torch.empty(total, _lib.STREAM_DWORDS, dtype=torch.float32, device=dev)
+    ws_bytes = int(lib.gsr_bin_lists_views_workspace_bytes(nv, pairs))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+
+    def whole(name):          # the array that holds all views
+        return getattr(first, name)._base
+
+    _call("gsr_bin_lists_views", lib.gsr_bin_lists_views, cviews, nv, _ptr(whole("order")), _ptr(whole("slot_base")),
+          _ptr(whole("slot_seq")), _ptr(whole("bbox")), _ptr(whole("ntiles")), _ptr(whole("rec")), pairs, _ptr(tile_offsets),
+          _ptr(tile_order), _ptr(sorted_gauss), _ptr(stream_rec), _ptr(ws), ws_bytes, stream)
+    for k, st in enumerate(states):
+        if not st.num_visible:
+            continue
+        b, I = int(bases[k]), max(st.num_pairs, 1)
+        st.tile_offsets, st.tile_order = tile_offsets[k], tile_order[k]
+        st.sorted_gauss, st.stream_rec = sorted_gauss[b:b + I], stream_rec[b:b + I]
+    return states
 
 
 def forward_composite(st: RenderState) -> RenderState:

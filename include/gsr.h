@@ -234,6 +234,24 @@ int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, const uint32
  * results do not depend on it. */
 int gsr_tile_order(const gsr_view *view_host, const uint32_t *tile_offsets, uint32_t *tile_order, void *stream);
 
+/* gsr_bin_lists + gsr_tile_order for num_views (1..8) views of the same Gaussians, image size and tile edge with one
+ * set of launches - the per-tile lists of all views of one optimisation step (GaussianRenderer.py:85-97 once per
+ * view).  Per view the results equal the one-view calls bit for bit.  The per-Gaussian inputs are the arrays of
+ * gsr_preprocess_fwd_views / gsr_bin_offsets_views (view k from k * n, slot_seq from k * (n + 1)); num_pairs: HOST array
+ * of the views' pair counts (read back from counters[k].num_pairs).  The per-pair outputs hold the views one after
+ * the other, view k from element pair_base[k] (gsr_bin_lists_views_layout fills pair_base, a multiple of 4096 each,
+ * and returns the total element count to allocate: sorted_gauss[total], stream_rec[total, GSR_STREAM_DWORDS]);
+ * tile_offsets[num_views, T+1]; tile_order[num_views, T] (may be NULL).
+ * gsr_bin_lists_views_supported: 1 when the views qualify - same sizes, and tile id, Gaussian index and emission slot
+ * fit one 64-bit word together - else 0 (use gsr_bin_lists per view). */
+int gsr_bin_lists_views_supported(const gsr_view *views_host, uint32_t num_views, const uint32_t *num_pairs);
+uint64_t gsr_bin_lists_views_layout(uint32_t num_views, const uint32_t *num_pairs, uint32_t *pair_base);
+size_t gsr_bin_lists_views_workspace_bytes(uint32_t num_views, const uint32_t *num_pairs);
+int gsr_bin_lists_views(const gsr_view *views_host, uint32_t num_views, const uint32_t *order, const uint32_t *slot_base,
+                        const uint32_t *slot_seq, const int32_t *bbox, const uint32_t *ntiles, const float *rec,
+                        const uint32_t *num_pairs, uint32_t *tile_offsets, uint32_t *tile_order, uint32_t *sorted_gauss,
+                        float *stream_rec, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- stage 3: compositing -------------------------------------------------------------
  * Replaces Utils/Probability.py:4-23 and GaussianRenderer.py:100-112 for every tile:
  * G = exp(-1/2 d^T Sigma^-1 d) at integer pixel coordinates, alpha = clamp(o*G, 0.01, 0.99),

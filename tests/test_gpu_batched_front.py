@@ -38,17 +38,23 @@ def _same(a, b, what):
     assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{what} differs"
 
 
+@pytest.mark.parametrize("lists", ["all views at once", "view by view"])
 @pytest.mark.parametrize("n,w,h,deg,nviews", [(3000, 200, 120, 3, 3), (70_001, 640, 360, 2, 8), (5, 64, 48, 0, 2),
                                                (200_000, 800, 800, 3, 11)])
-def test_batched_front_equals_the_one_view_calls(n, w, h, deg, nviews):
+def test_batched_front_equals_the_one_view_calls(n, w, h, deg, nviews, lists):
+    from gsplat_amd import _lib
     from gsplat_amd import rasterizer as R
     dev, params, views = _scene(n, w, h, deg, nviews)
     batched = R.forward_begin_views(*params, views)
     assert len(batched) == nviews
+    if lists == "all views at once":
+        for k in range(0, nviews, _lib.MAX_VIEWS):
+            R.forward_lists_views(batched[k:k + _lib.MAX_VIEWS])
     for k, view in enumerate(views):
         single = R.forward_begin(*params, None, view)
         R.forward_lists(single)
-        R.forward_lists(batched[k])
+        if lists == "view by view":
+            R.forward_lists(batched[k])
         assert (batched[k].num_visible, batched[k].num_pairs) == (single.num_visible, single.num_pairs), k
         for f in FIELDS:
             _same(getattr(batched[k], f), getattr(single, f), f"view {k}: {f}")
@@ -56,6 +62,14 @@ def test_batched_front_equals_the_one_view_calls(n, w, h, deg, nviews):
             _same(batched[k].tile_offsets, single.tile_offsets, f"view {k}: tile_offsets")
             _same(batched[k].sorted_gauss[:single.num_pairs], single.sorted_gauss[:single.num_pairs], f"view {k}: lists")
             _same(batched[k].stream_rec[:single.num_pairs], single.stream_rec[:single.num_pairs], f"view {k}: stream")
+            if lists == "all views at once":
+                # (the order inside a length class is unspecified: compare the lengths the two orders visit)
+                off = single.tile_offsets.cpu().long()
+                lens = off[1:] - off[:-1]
+                a, b = lens[batched[k].tile_order.cpu().long()], lens[single.tile_order.cpu().long()]
+                assert sorted(batched[k].tile_order.cpu().tolist()) == list(range(lens.numel()))
+                slack = int(lens.max()) // 1023 + 1
+                assert bool((a[:-1] + slack >= a[1:]).all()) and bool((b[:-1] + slack >= b[1:]).all())
 
 
 def test_minibatch_with_batched_front_is_bit_identical():
