@@ -355,9 +355,11 @@ constexpr uint32_t kGroupMaxWaves = 4;
 __host__ __device__ inline int group_waves(int S) { return S == 3 ? 3 : 4; }   // blocks per workgroup, S = blocks per tile edge
 
 // Where a wave of a tile group leaves its parts (unused by the other modes).
+typedef __attribute__((address_space(3))) float lds_float;      // (LDS pointers: 32-bit address arithmetic)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct GroupSlot {
-    float *parts;        // LDS [2][kGroupChunk][kGroupMaxWaves][GSR_PAIRGRAD_FLOATS]: the chunk being filled and the one before
-    uint32_t *slots;     // LDS [2][kGroupChunk]: emission slot of each entry
+    lds_float *parts;    // LDS [2][kGroupChunk][kGroupMaxWaves][GSR_PAIRGRAD_FLOATS]: the chunk being filled and the one before
+    lds_u32 *slots;      // LDS [2][kGroupChunk]: emission slot of each entry
     uint32_t block, blocks, entry;   // this wave's block inside the group, blocks of the group, entry of the chunk being filled
     uint32_t buf;        // chunk buffer being filled (0 / 1)
     uint32_t part, nparts;           // the group's row among the rows of a pair, rows per pair
@@ -375,8 +377,11 @@ __device__ inline void put_record(float *pairgrad, uint32_t rec_off, uint32_t la
             atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(pairgrad) + voff), val);
     } else if (MODE == kTileGroup) {
         const uint32_t e = gs.buf * kGroupChunk + gs.entry;
+        // (the entry's part of the index is wave-uniform and the lane's part never changes: a scalar multiply and one add)
+        const uint32_t lane_idx = gs.block * GSR_PAIRGRAD_FLOATS + (lane_off >> 2);
+        const uint32_t entry_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(e * (kGroupMaxWaves * GSR_PAIRGRAD_FLOATS)));
         if ((writers >> (threadIdx.x & 63)) & 1ull)
-            gs.parts[(e * kGroupMaxWaves + gs.block) * GSR_PAIRGRAD_FLOATS + (lane_off >> 2)] = val;
+            gs.parts[entry_idx + lane_idx] = val;
         if (gs.block == 0 && (threadIdx.x & 63) == 0) gs.slots[e] = rec_off / (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));
     } else {
         // every lane of the wave is active here: set the writers, store, restore.  The record's address is
@@ -400,7 +405,7 @@ __device__ inline void group_flush(GroupSlot &gs, uint32_t count, float *pairgra
     const uint32_t first = gs.buf * kGroupChunk;
     for (uint32_t i = threadIdx.x; i < count * GSR_PAIRGRAD_FLOATS; i += blockDim.x) {
         const uint32_t e = i / GSR_PAIRGRAD_FLOATS, f = i - e * GSR_PAIRGRAD_FLOATS;
-        const float *part = gs.parts + (first + e) * kGroupMaxWaves * GSR_PAIRGRAD_FLOATS + f;
+        const lds_float *part = gs.parts + (first + e) * kGroupMaxWaves * GSR_PAIRGRAD_FLOATS + f;
         float sum = part[0];
         for (uint32_t b = 1; b < gs.blocks; ++b) sum += part[b * GSR_PAIRGRAD_FLOATS];   // block order: reproducible
         pairgrad[((size_t)gs.slots[first + e] * gs.nparts + gs.part) * GSR_PAIRGRAD_FLOATS + f] = sum;
@@ -625,11 +630,12 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
 // MODE: how the blocks of a tile combine their sums (StoreMode above).
 // A wave none of whose pixels ran below kTinyT takes the plain sweep, the others the checked one.
 // Both live in one launch: the checked waves are few and three times as long, and a launch of their
-// own ran at the latency of a single wave per SIMD.  (Four waves per SIMD: the loop is bound by
-// instruction issue, more resident waves do not help it, and the register budget of four waves
-// holds both sweeps.)
+// own ran at the latency of a single wave per SIMD.  (Five waves per SIMD, 96 registers: a tile that is one block
+// runs the same with four - its loop is bound by instruction issue - but the tile groups, whose waves also wait
+// for each other at the chunk barriers, gain 5 % from the fifth (1.98 -> 1.87 ms per view at a tile edge of 64);
+// six waves would spill.)
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void composite_bwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                             const uint32_t *__restrict__ tile_order,
                                                             const float *__restrict__ stream_rec,
                                                             const float *__restrict__ final_T,
@@ -645,8 +651,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __shared__ float group_parts[2 * kGroupChunk * kGroupMaxWaves * GSR_PAIRGRAD_FLOATS];   // 12 KiB
         __shared__ uint32_t group_slots[2 * kGroupChunk];
         const int S = (v.L + 15) >> 4;
-        gs.parts = group_parts;
-        gs.slots = group_slots;
+        gs.parts = (lds_float *)group_parts;
+        gs.slots = (lds_u32 *)group_slots;
         gs.blocks = blockDim.x >> 6;                  // = group_waves(S): the launch made it so
         gs.block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         gs.nparts = (uint32_t)(S * S) / gs.blocks;
