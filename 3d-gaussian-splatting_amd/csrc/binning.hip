@@ -40,6 +40,17 @@ __device__ inline uint32_t seg_pick(const uint32_t (&a)[GSR_MAX_SEGS], uint32_t 
 struct PairBits {
     int slot, gauss;   // widths; the tile id starts at bit slot + gauss
 };
+// x / d for x below 2^24 (exact in fp32) from the reciprocal of d: the rounded product is off by one at most, which
+// the remainder shows.  A 32-bit integer division is some twenty vector instructions, this is seven.
+__device__ inline uint32_t div_below_2p24(uint32_t x, uint32_t d, float inv_d)
+{
+    if (x >= (1u << 24)) return x / d;
+    uint32_t q = (uint32_t)((float)x * inv_d);
+    const int32_t r = (int32_t)(x - q * d);
+    q = r < 0 ? q - 1u : (r >= (int32_t)d ? q + 1u : q);
+    return q;
+}
+
 __device__ inline uint64_t pack_pair(PairBits b, uint32_t tile, uint32_t gauss, uint32_t slot)
 {
     return ((uint64_t)tile << (b.slot + b.gauss)) | ((uint64_t)gauss << b.slot) | (uint64_t)slot;
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
         const int ox0 = __shfl(x0, lo, 64), oy0 = __shfl(y0, lo, 64), ony = __shfl(ny, lo, 64);
         if (pos < end) {
             const uint32_t local = pos - osb;
-            const uint32_t cx = local / (uint32_t)ony, cy = local - cx * (uint32_t)ony;
+            const uint32_t cx = div_below_2p24(local, (uint32_t)ony, __builtin_amdgcn_rcpf((float)ony)), cy = local - cx * (uint32_t)ony;
             const uint32_t tile = (uint32_t)(oy0 + (int)cy + v.nbh * (ox0 + (int)cx));
             if (tile_key) {
                 tile_key[pos] = tile;
@@ -123,47 +134,73 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(ViewK v, const uint32_t
     }
 }
 
-// True when alpha = clamp(opacity*G, 0.01, 0.99) is pinned at 0.01 on EVERY pixel of the tile
-// rectangle [x0,x1] x [y0,y1] (inclusive integer pixels), with a margin that covers the fp32
-// evaluation of the exponent in the compositing kernels.  The quadratic form is convex (checked),
-// so its minimum over the rectangle is 0 when the centre lies inside and otherwise sits on one of
-// the four edges.  The test is conservative: a pair it misses is simply evaluated in full.
+// Hint test of one block: bit 0 set when alpha = clamp(opacity*G, 0.01, 0.99) is pinned at 0.01 on EVERY pixel of
+// the rectangle [x0,x1] x [ya,ym] (the top rows of the block), bit 1 the same for [x0,x1] x [ym+1,yb] (inclusive
+// integer pixels; `top` / `bottom` false: that half has no pixels inside the tile and counts as clamped), with a
+// margin that covers the fp32 evaluation of the exponent in the compositing kernels.  The quadratic form is convex
+// (checked), so its minimum over a rectangle is 0 when the centre lies inside; otherwise it sits on an edge that
+// FACES the centre - along a ray from the centre the form grows, so a point of an edge that looks away from the
+// centre is beaten by the point where its ray entered the rectangle - and there is at most one such vertical and
+// one such horizontal edge.  Conservative: a half the test misses is simply evaluated in full.  Both halves share
+// the columns, hence everything that belongs to the vertical edge but the clamp of its minimiser.  Branch-free:
+// the lanes of a wave hold unrelated pairs.
+struct HalfRows {
+    float lo, hi;   // d = centre - pixel over the rows of the half: lo = gy - last row, hi = gy - first row
+};
+__device__ inline uint32_t block_halves_clamped_low(float gx, float gy, float A, float B, float D, float o, float x0, float x1,
+                                                    float ya, float ym, float yb, bool top, bool bottom)
+{
+    // A, B, D are the exp2-domain coefficients (negative-definite for a valid Gaussian)
+    const float a = -A, bh = -0.5f * B, d = -D;          // f(dx,dy) = a dx^2 + 2 bh dx dy + d dy^2 = -log2(G)
+    const bool convex = a > 0.0f && d > 0.0f && a * d > 1.000001f * bh * bh;
+    const float dx0 = gx - x1, dx1 = gx - x0;            // d = centre - pixel
+    const bool x_in = dx0 <= 0.0f && dx1 >= 0.0f;
+    const float ex = dx0 > 0.0f ? dx0 : dx1;             // the vertical edge that faces the centre (if !x_in)
+    // (hardware reciprocals, one ulp: the minimiser along an edge only has to be close - the form is evaluated AT
+    // it, and the slack below covers the rest)
+    const float bh2 = bh + bh;
+    const float t_free = -bh * ex * __builtin_amdgcn_rcpf(d);     // minimiser along dx = ex
+    const float over_a = -bh * __builtin_amdgcn_rcpf(a);
+    const float aex2 = a * ex * ex, bex2 = bh2 * ex;
+    const float mx = fmaxf(fabsf(dx0), fabsf(dx1));
+    const float amx2 = a * mx * mx, bmx2 = fabsf(bh2) * mx;
+    // raw < 0.01  <=>  log2(o) - f < log2(0.01); slack: rounding of f here and in the kernels
+    const float need = __log2f(o) + 1.0e-4f + 6.6438561898f;       // low  <=>  need + 4e-6 mag < fmin
+    const HalfRows rows[2] = {{gy - ym, gy - ya}, {gy - yb, gy - (ym + 1.0f)}};
+    uint32_t flags = 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float dy0 = rows[h].lo, dy1 = rows[h].hi;
+        const bool y_in = dy0 <= 0.0f && dy1 >= 0.0f;
+        const float t = fminf(fmaxf(t_free, dy0), dy1);
+        const float fx = fmaf(t, fmaf(d, t, bex2), aex2);                 // a ex^2 + 2 bh ex t + d t^2
+        const float ey = dy0 > 0.0f ? dy0 : dy1;                           // the horizontal edge that faces the centre
+        const float u = fminf(fmaxf(ey * over_a, dx0), dx1);
+        const float fy = fmaf(u, fmaf(a, u, bh2 * ey), d * ey * ey);      // a u^2 + 2 bh u ey + d ey^2
+        const float fmin = x_in ? (y_in ? 0.0f : fy) : (y_in ? fx : fminf(fx, fy));
+        const float my = fmaxf(fabsf(dy0), fabsf(dy1));
+        const float mag = fmaf(my, fmaf(d, my, bmx2), amx2);              // bound on the summed terms
+        const bool low = fmaf(4.0e-6f, mag, need) < fmin;
+        flags |= (low ? 1u : 0u) << h;
+    }
+    // opacity underflowed to 0: raw = 0 everywhere; a negative or NaN opacity, a form that is not convex: no hint
+    flags = o > 0.0f ? (convex ? flags : 0u) : (o == 0.0f ? 3u : 0u);
+    return flags | (top ? 0u : 1u) | (bottom ? 0u : 2u);
+}
+
+// the whole rectangle [x0,x1] x [y0,y1] at once (tiles of more than 16 blocks carry one answer for all blocks)
 __device__ inline bool tile_all_clamped_low(float gx, float gy, float A, float B, float D, float o, float x0,
                                             float x1, float y0, float y1)
 {
-    if (!(o > 0.0f)) return o == 0.0f;                  // opacity underflowed to 0: raw = 0 everywhere
-    // A, B, D are the exp2-domain coefficients (negative-definite for a valid Gaussian)
-    const float a = -A, bh = -0.5f * B, d = -D;          // f(dx,dy) = a dx^2 + 2 bh dx dy + d dy^2 = -log2(G)
-    if (!(a > 0.0f && d > 0.0f && a * d > 1.000001f * bh * bh)) return false;
-    const float dx0 = gx - x1, dx1 = gx - x0, dy0 = gy - y1, dy1 = gy - y0;   // d = centre - pixel
-    float fmin;
-    if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) {
-        fmin = 0.0f;
-    } else {
-        fmin = 3.0e38f;
-        const float ex[2] = {dx0, dx1}, ey[2] = {dy0, dy1};
-        // (hardware reciprocals, one ulp: the minimiser along an edge only has to be close - the form is
-        // evaluated AT it, and the slack below covers the rest; four correctly rounded divisions per test cost
-        // more vector instructions than everything else in this kernel)
-        const float over_d = -bh * __builtin_amdgcn_rcpf(d), over_a = -bh * __builtin_amdgcn_rcpf(a);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float t = fminf(fmaxf(ex[k] * over_d, dy0), dy1);         // edge dx = ex[k]
-            fmin = fminf(fmin, a * ex[k] * ex[k] + 2.0f * bh * ex[k] * t + d * t * t);
-            t = fminf(fmaxf(ey[k] * over_a, dx0), dx1);               // edge dy = ey[k]
-            fmin = fminf(fmin, a * t * t + 2.0f * bh * t * ey[k] + d * ey[k] * ey[k]);
-        }
-    }
-    const float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1));
-    const float mag = a * mx * mx + 2.0f * fabsf(bh) * mx * my + d * my * my;   // bound on the summed terms
-    // raw < 0.01  <=>  log2(o) - f < log2(0.01); slack: rounding of f here and in the kernels
-    return __log2f(o) - fmin + 4.0e-6f * mag + 1.0e-4f < -6.6438561898f;
+    return (block_halves_clamped_low(gx, gy, A, B, D, o, x0, x1, y0, y1, y1, true, false) & 1u) != 0u;
 }
 
 // One thread per sorted position p: write the owner's splat record in stream layout (with the
 // pair's emission slot and the hint flags: the halves of the tile's block on which alpha is 0.01
 // everywhere, where the compositing kernels can skip their exponentials), note the owner, mark tile
 // boundaries.
+// (ONE_BLOCK: the tile is a single 16x16 block, the headline case, without the loops over a tile's blocks)
+template <bool ONE_BLOCK>
 __global__ __launch_bounds__(256) void finalize_lists_kernel(
     ViewK v, const uint32_t *__restrict__ sorted_tile, const uint64_t *__restrict__ sorted_owner_slot,
     const float *__restrict__ rec, uint32_t num_pairs, uint32_t T, uint32_t *__restrict__ tile_offsets,
@@ -204,23 +241,23 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
     const uint32_t cur = packed ? (uint32_t)(word >> (bits.slot + bits.gauss)) : sorted_tile[p];
     uint32_t flags;
     {
-        const int xi = (int)(cur / (uint32_t)v.nbh), yi = (int)(cur - (uint32_t)xi * v.nbh);
+        const int xi = (int)div_below_2p24(cur, (uint32_t)v.nbh, __builtin_amdgcn_rcpf((float)v.nbh)), yi = (int)(cur - (uint32_t)xi * v.nbh);
         const float x0 = (float)(xi * v.L), y0 = (float)(yi * v.L);
         const float x1 = (float)(min((xi + 1) * v.L, v.W) - 1), y1 = (float)(min((yi + 1) * v.L, v.H) - 1);
         // bits 2c and 2c+1: the top and bottom 8 rows of the tile's c-th 16x16 block (c = bx * S + by,
         // the wave that composites it); a half that lies outside the tile counts as clamped
-        const int S = (v.L + 15) >> 4;
+        const int S = ONE_BLOCK ? 1 : (v.L + 15) >> 4;
         flags = 0u;
-        if (S <= 4) {
+        if (ONE_BLOCK) {
+            flags = block_halves_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, fminf(y0 + 7.0f, y1), y1, true, y0 + 7.0f < y1);
+        } else if (S <= 4) {
             for (int bx = 0; bx < S; ++bx) {
                 const float bx0 = x0 + 16.0f * (float)bx, bx1 = fminf(bx0 + 15.0f, x1);
                 for (int by = 0; by < S; ++by) {
-                    const float by0 = y0 + 16.0f * (float)by, bym = by0 + 7.0f, by1 = fminf(by0 + 15.0f, y1);
-                    const bool none = bx0 > x1 || by0 > y1;
-                    const bool low_top = none || tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, bx0, bx1, by0, fminf(bym, by1));
-                    const bool low_bottom = none || bym >= by1 ||
-                                            tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, bx0, bx1, bym + 1.0f, by1);
-                    flags |= ((low_top ? 1u : 0u) | (low_bottom ? 2u : 0u)) << (2 * (bx * S + by));
+                    const float by0 = y0 + 16.0f * (float)by, bym = fminf(by0 + 7.0f, y1), by1 = fminf(by0 + 15.0f, y1);
+                    const bool some = bx0 <= x1 && by0 <= y1;
+                    flags |= block_halves_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, bx0, bx1, by0, bym, by1, some, some && bym < by1)
+                             << (2 * (bx * S + by));
                 }
             }
         } else {
@@ -250,6 +287,13 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
         if (f < wave_f4) { typedef float v4f __attribute__((ext_vector_type(4))); const float4 t4 = wave_tile[f]; __builtin_nontemporal_store(v4f{t4.x, t4.y, t4.z, t4.w}, reinterpret_cast<v4f *>(&dst[f])); }
     }
 }
+
+// finalize_lists_kernel<true> for tiles of one block, <false> for larger tiles
+#define GSR_LAUNCH_FINALIZE(one_block, ...)                                        \
+    do {                                                                           \
+        if (one_block) hipLaunchKernelGGL(finalize_lists_kernel<true>, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(finalize_lists_kernel<false>, __VA_ARGS__);            \
+    } while (0)
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -475,7 +519,7 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, c
         if (int e = gsr_sort_words64(owner_slot, sorted_owner_slot, num_pairs, bits.slot + bits.gauss,
                                      bits.slot + bits.gauss + tile_bits, sort_ws, sort_bytes, stream, &in_first))
             return e;
-        hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
+        GSR_LAUNCH_FINALIZE(v.L <= 16, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
                            (const uint32_t *)nullptr, in_first ? owner_slot : sorted_owner_slot, rec, num_pairs, (uint32_t)v.T,
                            tile_offsets, pair_slot, sorted_gauss, stream_rec, bits, ListSegs{});
         return gsr_check_launch("bin_lists");
@@ -485,7 +529,7 @@ extern "C" int gsr_bin_lists(const gsr_view *view_host, const uint32_t *order, c
     if (int e = gsr_sort_pingpong64(tile_key, owner_slot, sorted_tile, sorted_owner_slot, num_pairs, 0, tile_bits, sort_ws,
                                     sort_bytes, stream, &in_first))
         return e;
-    hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
+    GSR_LAUNCH_FINALIZE(v.L <= 16, dim3(gsr_div_up(num_pairs, 256)), dim3(256), 0, st, v,
                        in_first ? tile_key : sorted_tile, in_first ? owner_slot : sorted_owner_slot, rec, num_pairs,
                        (uint32_t)v.T, tile_offsets, pair_slot, sorted_gauss, stream_rec, bits, ListSegs{});
     return gsr_check_launch("bin_lists");
@@ -589,7 +633,7 @@ extern "C" int gsr_bin_lists_views(const gsr_view *views_host, uint32_t num_view
     if (int e = gsr_sort_words64_segs(words, words_b, segs.n, segs.base, num_views, bits.slot + bits.gauss,
                                       bits.slot + bits.gauss + tile_bits, sort_ws, workspace_bytes - 2 * arr, stream, &in_first))
         return e;
-    hipLaunchKernelGGL(finalize_lists_kernel, dim3(gsr_div_up(most, 256), num_views), dim3(256), 0, st, v, (const uint32_t *)nullptr,
+    GSR_LAUNCH_FINALIZE(v.L <= 16, dim3(gsr_div_up(most, 256), num_views), dim3(256), 0, st, v, (const uint32_t *)nullptr,
                        in_first ? words : words_b, rec, 0u, (uint32_t)v.T, tile_offsets, (uint32_t *)nullptr, sorted_gauss, stream_rec,
                        bits, segs);
     if (tile_order)

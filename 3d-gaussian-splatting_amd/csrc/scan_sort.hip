@@ -281,6 +281,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     }
     const int word_shift = shift;   // WORDS: position of the digit inside the 64-bit word
     if (WORDS) shift = 0;
+    const int digit_bits = __popc(mask);
     digit_total += (size_t)blockIdx.y * RADIX_SIZE;
     // first position of digit d in the output: exclusive scan of the 256 digit totals
     uint32_t digit_base;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < RADIX_BITS; ++b) {
+            if (WORDS && b >= digit_bits) break;   // (a digit of fewer than eight bits: the others are zero in every lane)
             const bool bit = (d >> b) & 1u;
             const unsigned long long bal = __ballot(bit);
             peers &= bit ? bal : ~bal;
@@ -550,6 +552,14 @@ static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_
     return gsr_check_launch("sort_pairs");
 }
 
+// Bits of the next digit when the bits [bit, end_bit) are split evenly over as few passes of at most RADIX_BITS as
+// they need (13 tile bits: 7 + 6 instead of 8 + 5).  The scatter kernel ranks a digit with one ballot per bit.
+static int even_digit_bits(int bit, int end_bit)
+{
+    const int left = end_bit - bit, passes = (left + RADIX_BITS - 1) / RADIX_BITS;
+    return (left + passes - 1) / passes;
+}
+
 // 64-bit words sorted (stably) by their bits [begin_bit, end_bit): ping-pong between words_a and words_b as above.
 int gsr_sort_words64(uint64_t *words_a, uint64_t *words_b, uint32_t n, int begin_bit, int end_bit, void *workspace,
                      size_t workspace_bytes, void *stream, bool *result_in_first)
@@ -570,8 +580,8 @@ int gsr_sort_words64(uint64_t *words_a, uint64_t *words_b, uint32_t n, int begin
     uint32_t *hist = (uint32_t *)workspace;
     uint32_t *digit_total = (uint32_t *)((char *)workspace + align256((size_t)nb * RADIX_SIZE * sizeof(uint32_t)));
     uint64_t *wi = words_a, *wo = words_b;
-    for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
-        const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
+    for (int bit = begin_bit, nbits; bit < end_bit; bit += nbits) {
+        nbits = even_digit_bits(bit, end_bit);
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel<uint64_t>, dim3(nb), dim3(SORT_THREADS), 0, st, wi, n, bit, mask, nb, hist, no_segs);
         hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE), dim3(256), 0, st, hist, nb, digit_total, no_segs);
@@ -622,8 +632,8 @@ int gsr_sort_words64_segs(uint64_t *words_a, uint64_t *words_b, const uint32_t *
     uint32_t *hist = (uint32_t *)workspace;
     uint32_t *digit_total = (uint32_t *)((char *)workspace + align256((size_t)blocks * RADIX_SIZE * sizeof(uint32_t)));
     uint64_t *wi = words_a, *wo = words_b;
-    for (int bit = begin_bit; bit < end_bit; bit += RADIX_BITS) {
-        const int nbits = end_bit - bit < RADIX_BITS ? end_bit - bit : RADIX_BITS;
+    for (int bit = begin_bit, nbits; bit < end_bit; bit += nbits) {
+        nbits = even_digit_bits(bit, end_bit);
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel<uint64_t>, dim3(most, count), dim3(SORT_THREADS), 0, st, wi, 0u, bit, mask, 0u, hist, segs);
         hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE, count), dim3(256), 0, st, hist, 0u, digit_total, segs);
