@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(CSRC, "libgsr.so")
 
 REC_FLOATS = 12
 STREAM_DWORDS = 16
-PAIRGRAD_FLOATS = 9
+PAIRGRAD_FLOATS = 12
 MAX_VIEWS = 8
 ADAM_MAX_TENSORS = 8
 

@@ -291,22 +291,6 @@ __device__ inline float dpp_add(float val)
     return val + __int_as_float(moved);
 }
 constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
-constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;   // last lane of the row before / of row 1, to the rows of the row mask
-
-// val + (the value DPP control CTRL moves in), in the rows of ROW_MASK only; the other rows keep val.  One
-// instruction: the add writes its own source register, and rows outside the mask are left alone.  (The two wait
-// states a DPP read needs after a vector write of the same register are inside the statement: the compiler pads its
-// own instructions only.)
-template <int CTRL, int ROW_MASK>
-__device__ inline float dpp_add_rows(float val)
-{
-    static_assert(CTRL == 0x142 || CTRL == 0x143, "row_bcast:15 or row_bcast:31");
-    if (CTRL == 0x142)
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:%1 bank_mask:0xf" : "+v"(val) : "n"(ROW_MASK));
-    else
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:%1 bank_mask:0xf" : "+v"(val) : "n"(ROW_MASK));
-    return val;
-}
 
 // lanes 0..31: a[l] + a[l+32];  lanes 32..63: b[l-32] + b[l]
 __device__ inline float merge_halves(float a, float b)
@@ -330,33 +314,26 @@ __device__ inline float merge_half_rows(float a, float b)
 // every lane ends with the sum over its group of 8 (resp. its row of 16)
 __device__ inline float sum8(float x) { return dpp_add<DPP_HALF_MIRROR>(dpp_add<DPP_QUAD_2301>(dpp_add<DPP_QUAD_1032>(x))); }
 __device__ inline float sum16(float x) { return dpp_add<DPP_MIRROR>(sum8(x)); }
-// the lanes of the last row (48..63) end with the sum over the wave; x: one value per row, the same on all its lanes
-__device__ inline float sum_rows_into_last(float x)
-{
-    return dpp_add_rows<DPP_ROW_BCAST31, 0xC>(dpp_add_rows<DPP_ROW_BCAST15, 0xA>(x));   // rows 1, 3 += rows 0, 2; rows 2, 3 += row 1
-}
 
-// Which lane writes which float of a gradient record (nine floats), fixed per lane.
-// Full records: group g of 8 lanes (g = lane / 8) holds record float g, the last row of lanes the blue sum,
-// record float 8 (written by lane 49).
+// Which lane writes which float of a gradient record, fixed per lane.
+// Full records: group g of 8 lanes (g = lane / 8) holds record float g, row r (r = lane / 16) holds
+// the row's part of the blue sum, record float 8 + r.
 // Colour-only records: after merge_halves(red, green) and merge_rows(.., blue) the rows hold red,
-// blue(rows 0-1), green, blue(rows 2-3), and the last row takes the second row's part on top of its own:
-// floats 6 (lane 6), 7 (lane 39), 8 (lane 56); the other six floats are zeros (lanes 0..5).
-// The nine writers of a record store with ONE instruction under a constant exec mask.
-constexpr int kBlueLane = 49;
-constexpr unsigned long long kFullWriters = 0x0101010101010101ull | (1ull << kBlueLane);   // lanes 8 g and the blue lane
-constexpr unsigned long long kColWriters = 0x7Full | (1ull << 39) | (1ull << 56);
+// blue (rows 0-1), green, blue (rows 2-3): floats 6, 8, 7, 9; the other eight floats are zeros.
+// The twelve writers of a record store with ONE instruction under a constant exec mask.
+constexpr unsigned long long kFullWriters = 0x0103010301030103ull;   // lanes 8 g and lanes 16 r + 1
+constexpr unsigned long long kColWriters = (0x7Full | (3ull << 10)) | (1ull << 24) | (1ull << 39) | (1ull << 57);
 struct RecordLanes {
     uint32_t full_off, col_off;   // byte offset of the lane's float inside a record
     bool full_main, col_zero;     // the lane holds one of the 8 merged sums / writes a zero
-    float colour;                 // 1 on the three lanes that write a colour float of a full record (floats 6..8), else 0
+    float colour;                 // 1 on the six lanes that write a colour float of a full record (floats 6..11), else 0
 };
 __device__ inline RecordLanes record_lanes(int lane)
 {
     RecordLanes L;
     L.full_main = (lane & 7) == 0;
-    L.full_off = 4u * (L.full_main ? (uint32_t)(lane >> 3) : 8u);
-    L.col_zero = lane < 6;
+    L.full_off = 4u * (L.full_main ? (uint32_t)(lane >> 3) : 8u + (uint32_t)(lane >> 4));
+    L.col_zero = lane < 6 || lane == 10 || lane == 11;
     L.col_off = 4u * (uint32_t)(lane & 15);
     L.colour = (((kFullWriters >> lane) & 1ull) && L.full_off >= 24u) ? 1.0f : 0.0f;
     return L;
@@ -446,7 +423,7 @@ __device__ inline float mul_zero_wins(float a, float b)
 }
 
 // Full record, floats: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y, sum h v_y^2, dL/d(opacity),
-// dL/d(red), dL/d(green), dL/d(blue).
+// dL/d(red), dL/d(green), then four partial sums of dL/d(blue).
 // Returns, on every writer lane of a full record, the float that lane stores (before any rescaling).
 __device__ inline float reduce_full(const RecordLanes &L, float vx, float vy, float xx, float xy, float yy, float o, float r, float g, float b)
 {
@@ -455,7 +432,7 @@ __device__ inline float reduce_full(const RecordLanes &L, float vx, float vy, fl
     const float n0 = merge_rows(m0, m1);   // rows: vx, xx, yy, r
     const float n1 = merge_rows(m2, m3);   // rows: vy, xy, o,  g
     const float all8 = sum8(merge_half_rows(n0, n1));
-    const float blue = sum_rows_into_last(sum16(b));
+    const float blue = sum16(b);
     return L.full_main ? all8 : blue;
 }
 
@@ -464,8 +441,7 @@ template <int MODE>
 __device__ inline void reduce_store_colour(const RecordLanes &L, float *pairgrad, uint32_t rec_off, const GroupSlot &gs, float r,
                                            float g, float b)
 {
-    float rows = sum16(merge_rows(merge_halves(r, g), b));   // rows: red, blue(0-1), green, blue(2-3)
-    rows = dpp_add_rows<DPP_ROW_BCAST31, 0x8>(rows);         // last row: blue
+    const float rows = sum16(merge_rows(merge_halves(r, g), b));   // rows: red, blue(0-1), green, blue(2-3)
     put_record<MODE>(pairgrad, rec_off, L.col_off, L.col_zero ? 0.0f : rows, kColWriters, gs);
 }
 
@@ -484,8 +460,8 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     // U_c(k) = sum over the block's pixels of T_k g_c (T_k: transmittance in front of entry k, g_c: the pixel's
     // cotangent in channel c), every entry has  U_c(k) = U_c(k+1) + dL/dc_k  (T_k = T_{k+1} + alpha_k T_k, and
     // dL/dc_k = sum alpha_k T_k g_c), and an entry with alpha = 0.01 everywhere has  dL/dc_k = 0.01 U_c(k) =
-    // (0.01 / 0.99) U_c(k+1).  U is kept on the three lanes that store the colour floats of a record (red,
-    // green, blue) and follows from the sums
+    // (0.01 / 0.99) U_c(k+1).  U is kept on the six lanes that store the colour floats of a record (in the
+    // record's layout: red, green, four partial sums of blue over the rows of lanes) and follows from the sums
     // every other entry reduces anyway.
     const float low_gain = lanes.colour * (kAlphaMin / (1.0f - kAlphaMin));
     float U = 0.0f;
@@ -672,7 +648,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     raise_wave_priority(w, v.T);
     GroupSlot gs = {nullptr, nullptr, 0u, 1u, 0u, 0u, 0u, 1u};
     if (MODE == kTileGroup) {
-        __shared__ float group_parts[2 * kGroupChunk * kGroupMaxWaves * GSR_PAIRGRAD_FLOATS];   // 9 KiB
+        __shared__ float group_parts[2 * kGroupChunk * kGroupMaxWaves * GSR_PAIRGRAD_FLOATS];   // 12 KiB
         __shared__ uint32_t group_slots[2 * kGroupChunk];
         const int S = (v.L + 15) >> 4;
         gs.parts = (lds_float *)group_parts;

@@ -399,7 +399,8 @@ __device__ inline void put(float *dst, float v)
     if (ACC) *dst += v; else *dst = v;
 }
 
-// Sum of each Gaussian's per-tile gradient records (nine floats each) -> gsum[N,12] (9 used).  The records of
+// Sum of each Gaussian's per-tile gradient records -> gsum[N,12] (9 used; the last four floats of a
+// record are partial sums of one quantity).  The records of
 // Gaussian g are the contiguous slots slot_base[g] .. slot_base[g]+ntiles[g] of pairgrad.  One
 // thread per Gaussian walks its slots in order; a Gaussian with many tiles is summed by the whole
 // wave (strided partial sums, then a fixed butterfly), so one huge splat cannot serialise thousands
@@ -408,17 +409,15 @@ constexpr uint32_t kHeavyTiles = 96;
 
 __device__ inline void add_record(double (&acc)[9], const float *__restrict__ pairgrad, uint32_t slot)
 {
-    // nine floats at a stride of 36 bytes: three 12-byte loads (a record is only 4-byte aligned)
-    typedef float f3 __attribute__((ext_vector_type(3), aligned(4)));
-    const float *src = pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS;   // (a vector of three floats is padded to sixteen bytes)
-    const f3 a = *reinterpret_cast<const f3 *>(src), b = *reinterpret_cast<const f3 *>(src + 3), c = *reinterpret_cast<const f3 *>(src + 6);
-    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z;
-    acc[3] += b.x; acc[4] += b.y; acc[5] += b.z;
-    acc[6] += c.x; acc[7] += c.y; acc[8] += c.z;
+    const float4 *src = reinterpret_cast<const float4 *>(pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS);
+    const float4 a = src[0], b = src[1], c = src[2];
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    acc[8] += ((double)c.x + (double)c.y) + ((double)c.z + (double)c.w);   // blue arrives as four partial sums
 }
 
 // Four lanes per Gaussian: lane q of the four takes the records q, q+4, ... of its Gaussian (neighbouring
-// lanes read neighbouring 36-byte records) and the four partial sums meet in two shuffle steps.  With
+// lanes read neighbouring 48-byte records) and the four partial sums meet in two shuffle steps.  With
 // one lane per Gaussian every lane walks its own records one after the other and the kernel waits on
 // memory latency: a Gaussian has five records on average.
 // (Walking the Gaussians in depth order, in which their records are consecutive in memory, was

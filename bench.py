@@ -61,7 +61,7 @@ def algorithmic_bytes(n, m, pairs, pixels, k_sh, views=1, parts=1):
     k_sh active SH coefficients per channel.  All per view, except "preprocess_bwd_views": ONE launch chains the
     per-Gaussian sums of `views` views to the raw parameters - it reads the parameters and writes the dense
     gradients once per step, and reads 48 bytes of sums + the mask and writes the 12-byte screen gradient per view.
-    "pair_reduce" reads the per-pair gradient records (36 bytes, `parts` rows per pair) and writes the sums.
+    "pair_reduce" reads the per-pair gradient records (48 bytes, `parts` rows per pair) and writes the sums.
     "preprocess_fwd_views" is stage 1 of all `views` views in ONE launch (the parameters are read once), here
     divided by the number of views so that it compares with a per-view time."""
     return {
@@ -70,7 +70,7 @@ def algorithmic_bytes(n, m, pairs, pixels, k_sh, views=1, parts=1):
         "binning_sort": m * 16 + pairs * 12 + 2 * pairs * 12 + pairs * 8,
         "composite_fwd": pairs * (4 + 40) + pixels * 12 + pixels * 4,
         "composite_bwd": pairs * 44 + pixels * (12 + 12 + 8) + m * 40,
-        "pair_reduce": pairs * parts * 36 + n * 9 + n * 48,
+        "pair_reduce": pairs * parts * 48 + n * 9 + n * 48,
         "preprocess_bwd_views": n * (44 + 12 * k_sh) + n * 236 + views * n * (48 + 1 + 12),
     }
 

@@ -74,8 +74,8 @@ typedef struct gsr_counters {
 /* Per-(tile,Gaussian) gradient record produced by the compositing backward. */
 /* With h = -2 dL/d(exponent) per pixel, d = centre - pixel and v = inverse covariance * d:
  * sum h v_x, sum h v_y, sum h v_x v_x, sum h v_x v_y, sum h v_y v_y, dL/d(opacity), dL/d(r), dL/d(g),
- * dL/d(b): nine floats, 36 bytes, rows packed without padding */
-#define GSR_PAIRGRAD_FLOATS 9
+ * then FOUR partial sums whose total is dL/d(b) */
+#define GSR_PAIRGRAD_FLOATS 12
 
 const char *gsr_last_error(void);
 int gsr_version(void);
@@ -262,7 +262,7 @@ int gsr_composite_fwd(const gsr_view *view_host, const uint32_t *tile_offsets, c
                       const float *stream_rec, float *img, float *final_T, void *stream);
 
 /* Backward of the blend (autograd of the statements above).  dimg[W,H,3] is dL/dimg.
- * pairgrad[I * parts, GSR_PAIRGRAD_FLOATS], parts = gsr_pairgrad_parts(tile_length), is fully overwritten: the pair at sorted
+ * pairgrad[I * parts, 12], parts = gsr_pairgrad_parts(tile_length), is fully overwritten: the pair at sorted
  * position p with emission slot s (its stream record's slot field, = pair_slot[p]) owns the rows
  * parts * s .. parts * s + parts - 1, whose sum is its gradient record.  parts is 1 when a tile is one 16x16
  * block (tile_length <= 16) and 1, 3 or 4 for tiles of 4, 9 or 16 blocks (the reference's default tile edge

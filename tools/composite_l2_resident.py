@@ -42,7 +42,7 @@ view = _lib.make_view(1, 3, W, H, 16, [0.0] * 16, [0.0] * 16, [0.0] * 3)
 img = torch.empty(W, H, 3, device=dev); fT = torch.empty(W, H, device=dev)
 dimg = torch.rand(W, H, 3, device=dev)
 I = 4 * n_list
-pairgrad = torch.empty(I, 9, device=dev)
+pairgrad = torch.empty(I, 12, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 def fwd(): _lib.check(lib.gsr_composite_fwd(view, tile_offsets.data_ptr(), None, stream.data_ptr(), img.data_ptr(), fT.data_ptr(), s), "fwd")
 def bwd(): _lib.check(lib.gsr_composite_bwd(view, tile_offsets.data_ptr(), None, stream.data_ptr(), fT.data_ptr(), dimg.data_ptr(), I, pairgrad.data_ptr(), s), "bwd")

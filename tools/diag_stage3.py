@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 pg = st.pairgrad.cpu().numpy().astype(np.float64)[:st.num_pairs]
 owner = np.zeros(st.num_pairs, np.int64)     # pairgrad rows are in emission-slot order
 owner[st.pair_slot.cpu().numpy()[:st.num_pairs]] = st.sorted_gauss.cpu().numpy()[:st.num_pairs]
-S = np.zeros((n, pg.shape[1])); np.add.at(S, owner, pg)
+S = np.zeros((n, 12)); np.add.at(S, owner, pg)
 o32 = oracle.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], deg, w, h, tile, a["w2m"], a["proj"], a["cam_pos"], dimg=cot)
 o64 = oracle.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], deg, w, h, tile, a["w2m"], a["proj"], a["cam_pos"], dimg=cot, precise=True)
 def D_from_conicgrad(o):
