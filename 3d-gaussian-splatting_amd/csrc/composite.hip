@@ -126,6 +126,7 @@ __device__ inline void rec_request(const float *__restrict__ stream_rec, uint32_
     asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(R.d) : "s"(stream_rec), "s"(off) : "memory");
 }
 __device__ inline void rec_wait(Rec &R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.d)::"memory"); }
+__device__ inline void rec_wait(Rec &R, Rec &Q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.d), "+s"(Q.d)::"memory"); }
 
 // A wave-uniform address as a pair of scalar registers.  Where the compiler does not see that a stream offset
 // is uniform it computes the address on the vector ALU and this reads it back with v_readfirstlane; where it
@@ -247,21 +248,38 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
         const uint32_t touch_floor = min(64u, off_stream_last);
         uint32_t off = w.begin * 64u;
         const uint32_t n = w.end - w.begin;
-        Rec A, B;
+        // Four record buffers, two fetches in flight while two records are blended: a wave waits for ALL its scalar
+        // loads at once (they may return out of order), so with one fetch per wait a run of clamped entries - ten
+        // vector instructions each - leaves eight waves per SIMD short of work for the 500 cycles a fetch from L2
+        // takes; two fetches per wait halve the waits.  (The backward has no scalar registers left for this.)
+        Rec A, B, C, D;
         rec_request(stream_rec, off, A);
-        for (uint32_t i = n >> 1; i != 0; --i) {
-            rec_wait(A);
-            rec_request(stream_rec, off + 64u, B);
+        rec_request(stream_rec, min(off + 64u, off_last), B);
+        for (uint32_t i = n >> 2; i != 0; --i) {
+            rec_wait(A, B);
+            rec_request(stream_rec, min(off + 128u, off_last), C);
+            rec_request(stream_rec, min(off + 192u, off_last), D);
             l2_touch(stream_rec, max(min(off + kTouchAhead * 64u, off_stream_last), touch_floor) - touch_back, touch_off, sink);
             blend(A);
-            rec_wait(B);
-            rec_request(stream_rec, min(off + 128u, off_last), A);   // (the last record again after the last pair)
             blend(B);
-            off += 128u;
+            rec_wait(C, D);
+            rec_request(stream_rec, min(off + 256u, off_last), A);   // (the last record again past the end of the list)
+            rec_request(stream_rec, min(off + 320u, off_last), B);
+            l2_touch(stream_rec, max(min(off + (kTouchAhead + 2u) * 64u, off_stream_last), touch_floor) - touch_back, touch_off, sink);
+            blend(C);
+            blend(D);
+            off += 256u;
         }
-        rec_wait(A);
+        rec_wait(A, B);
         l2_touch_drain(sink);   // before any other code: once the loop is left the compiler may reuse the sink's register
-        if (n & 1u) blend(A);
+        const uint32_t rest = n & 3u;
+        if (rest >= 1u) blend(A);
+        if (rest >= 2u) blend(B);
+        if (rest == 3u) {
+            rec_request(stream_rec, off + 128u, C);
+            rec_wait(C);
+            blend(C);
+        }
     }
     if (!w.vx) return;
 #pragma unroll
