@@ -619,6 +619,38 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     Rec A, B;
     const uint32_t n = w.end - w.begin;
     rec_request(stream_rec, off, A);
+    if (!CHECK && MODE == kOneBlock) {
+        // plain sweep of a one-block tile: four record buffers, two fetches in flight per wait (see composite_fwd_kernel)
+        auto back = [&](uint32_t records) { return max(off, off_first + records * 64u) - records * 64u; };   // (the first record again past the front)
+        Rec C, D;
+        rec_request(stream_rec, back(1u), B);
+        for (uint32_t i = n >> 2; i != 0; --i) {
+            rec_wait(A, B);
+            rec_request(stream_rec, back(2u), C);
+            rec_request(stream_rec, back(3u), D);
+            l2_touch(stream_rec, max(off, (kTouchAhead + 1) * 64u) - (kTouchAhead + 1) * 64u, touch_off, sink);
+            entry(A, k);
+            entry(B, k);
+            rec_wait(C, D);
+            rec_request(stream_rec, back(4u), A);
+            rec_request(stream_rec, back(5u), B);
+            l2_touch(stream_rec, max(off, (kTouchAhead + 3) * 64u) - (kTouchAhead + 3) * 64u, touch_off, sink);
+            entry(C, k);
+            entry(D, k);
+            off = back(4u);
+        }
+        rec_wait(A, B);
+        l2_touch_drain(sink);
+        const uint32_t rest = n & 3u;
+        if (rest >= 1u) entry(A, k);
+        if (rest >= 2u) entry(B, k);
+        if (rest == 3u) {
+            rec_request(stream_rec, back(2u), C);
+            rec_wait(C);
+            entry(C, k);
+        }
+        return;
+    }
     // two entries per turn and a single exit: the registers of the running sums stay put (a loop that can also
     // end between the two entries made the compiler copy all of them twice per turn)
     for (uint32_t i = n >> 1; i != 0; --i) {
