@@ -36,7 +36,9 @@ constexpr float kAlphaMax = 0.99f;
 constexpr float kTinyT = 1e-26f;
 constexpr float kMinNormalT = 1.17549435e-38f;   // FLT_MIN
 constexpr float kRescue = 1099511627776.0f;      // 2^40: FLT_MIN * 2^40 > kTinyT
-constexpr uint32_t kTouchAhead = 16;   // records (768 bytes) between the L2 touch and the scalar fetch
+// records between the L2 touch and the scalar fetch in the forward and in the backward (the forward alone is 3 %
+// faster with 8 than with 16 and slower again below 6; the backward runs the same from 2 to 16)
+constexpr uint32_t kTouchAhead = 8, kTouchAheadBwd = 16;
 
 struct WaveGeom {
     int tile, x, y0;     // pixel column and first row of this lane; its rows are y0 + 4 j, j = 0..3
@@ -628,13 +630,13 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             rec_wait(A, B);
             rec_request(stream_rec, back(2u), C);
             rec_request(stream_rec, back(3u), D);
-            l2_touch(stream_rec, max(off, (kTouchAhead + 1) * 64u) - (kTouchAhead + 1) * 64u, touch_off, sink);
+            l2_touch(stream_rec, max(off, (kTouchAheadBwd + 1) * 64u) - (kTouchAheadBwd + 1) * 64u, touch_off, sink);
             entry(A, k);
             entry(B, k);
             rec_wait(C, D);
             rec_request(stream_rec, back(4u), A);
             rec_request(stream_rec, back(5u), B);
-            l2_touch(stream_rec, max(off, (kTouchAhead + 3) * 64u) - (kTouchAhead + 3) * 64u, touch_off, sink);
+            l2_touch(stream_rec, max(off, (kTouchAheadBwd + 3) * 64u) - (kTouchAheadBwd + 3) * 64u, touch_off, sink);
             entry(C, k);
             entry(D, k);
             off = back(4u);
@@ -657,7 +659,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         rec_wait(A);
         rec_request(stream_rec, off - 64u, B);
         // the two lines below the one sixteen entries down (never below the start of the stream)
-        l2_touch(stream_rec, max(off, (kTouchAhead + 1) * 64u) - (kTouchAhead + 1) * 64u, touch_off, sink);
+        l2_touch(stream_rec, max(off, (kTouchAheadBwd + 1) * 64u) - (kTouchAheadBwd + 1) * 64u, touch_off, sink);
         entry(A, k);
         if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
         rec_wait(B);
