@@ -415,8 +415,9 @@ extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint
         return e;
     if (!in_first) { gsr_set_error("gsr_bin_offsets: unexpected number of sort passes"); return GSR_ERR_LAUNCH; }
     // slot_base[order[s]] = sum over s' < s of ntiles[order[s']]
+    // (keys_b, the sort's second key buffer, is free again: the scan keeps the gathered tile counts there)
     if (int e = gsr_exclusive_scan_along(ntiles, order, slot_base, n, &counters->num_pairs, scan_ws, scan_bytes, stream,
-                                         slot_seq, &counters->error))
+                                         slot_seq, &counters->error, keys_b))
         return e;
     return gsr_check_launch("bin_offsets");
 }
@@ -463,7 +464,7 @@ extern "C" int gsr_bin_offsets_views(uint32_t *depth_key, const uint32_t *ntiles
     if (!in_first) { gsr_set_error("gsr_bin_offsets_views: unexpected number of sort passes"); return GSR_ERR_LAUNCH; }
     if (int e = gsr_exclusive_scan_along_batch(ntiles, order, slot_base, n, num_views, &counters->num_pairs, &counters->error,
                                                (uint32_t)(sizeof(gsr_counters) / sizeof(uint32_t)), scan_ws, scan_bytes, stream,
-                                               slot_seq))
+                                               slot_seq, keys_b))
         return e;
     return gsr_check_launch("bin_offsets_views");
 }

@@ -39,10 +39,12 @@ int gsr_sort_pingpong32_batch(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys
                               bool *result_in_first);   // nseq sequences of n pairs, one after the other
 int gsr_exclusive_scan_along_batch(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t nseq,
                                    uint32_t *total, uint32_t *overflow_flag, uint32_t counter_stride, void *workspace,
-                                   size_t workspace_bytes, void *stream, uint32_t *out_seq);
+                                   size_t workspace_bytes, void *stream, uint32_t *out_seq,
+                                   uint32_t *gathered /* n * nseq words of scratch for in[idx[i]] in sequence order; may be null */);
 int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
                              void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq,
-                             uint32_t *overflow_flag /* bit 1 raised when the total does not fit 32 bits; may be null */);
+                             uint32_t *overflow_flag /* bit 1 raised when the total does not fit 32 bits; may be null */,
+                             uint32_t *gathered /* n words of scratch, may be null */);
 
 extern "C" uint32_t gsr_pairgrad_parts(int tile_length);
 

@@ -60,14 +60,18 @@ struct SegCounters {
 
 // With idx != null element i of the sequence is in[idx[i]] and its result goes to out[idx[i]]
 // (a scan along a permutation; in and out may then not alias).
+// gathered (may be null, only with idx): the elements in sequence order, gathered[i] = in[idx[i]], written here so
+// that scan_apply_kernel reads them in order instead of gathering a second time.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t *__restrict__ in,
                                                                    const uint32_t *__restrict__ idx, uint32_t n,
-                                                                   uint32_t *__restrict__ block_sums, SegCounters cnt)
+                                                                   uint32_t *__restrict__ block_sums, SegCounters cnt,
+                                                                   uint32_t *__restrict__ gathered)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
     __shared__ unsigned long long wide;
     in += (size_t)blockIdx.y * n;
     if (idx) idx += (size_t)blockIdx.y * n;
+    if (gathered) gathered += (size_t)blockIdx.y * n;
     block_sums += (size_t)blockIdx.y * gridDim.x;
     uint32_t *overflow_flag = cnt.overflow_flag ? cnt.overflow_flag + (size_t)blockIdx.y * cnt.stride : nullptr;
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
     for (int k = 0; k < SCAN_ITEMS; ++k)
         if (base + k < n) {
             const uint32_t x = in[idx ? idx[base + k] : base + k];
+            if (gathered) gathered[base + k] = x;
             s += x;
             s64 += x;
         }
@@ -129,12 +134,15 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ 
 
 // out_seq (may be null): the same prefix sums in SEQUENCE order, out_seq[i] for i < n and the total at
 // out_seq[n]
+// gathered (may be null): the elements in sequence order, as scan_reduce_kernel left them - read in place of in[idx[i]]
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t *in, const uint32_t *__restrict__ idx,
                                                                   uint32_t *out, uint32_t n,
                                                                   const uint32_t *__restrict__ block_sums,
-                                                                  uint32_t *__restrict__ out_seq)
+                                                                  uint32_t *__restrict__ out_seq,
+                                                                  const uint32_t *__restrict__ gathered)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+    if (gathered) gathered += (size_t)blockIdx.y * n;
     in += (size_t)blockIdx.y * n;
     out += (size_t)blockIdx.y * n;
     if (idx) idx += (size_t)blockIdx.y * n;
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         at[k] = base + k < n ? (idx ? idx[base + k] : base + k) : 0u;
-        v[k] = base + k < n ? in[at[k]] : 0u;
+        v[k] = base + k < n ? (gathered ? gathered[base + k] : in[at[k]]) : 0u;
         s += v[k];
     }
     uint32_t total;
@@ -407,7 +415,7 @@ extern "C" size_t gsr_scan_workspace_bytes(uint32_t n)
 // the next one's.  The workspace holds nseq times gsr_scan_workspace_bytes(n).
 int gsr_exclusive_scan_along_batch(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t nseq,
                                    uint32_t *total, uint32_t *overflow_flag, uint32_t counter_stride, void *workspace,
-                                   size_t workspace_bytes, void *stream, uint32_t *out_seq)
+                                   size_t workspace_bytes, void *stream, uint32_t *out_seq, uint32_t *gathered)
 {
     hipStream_t st = (hipStream_t)stream;
     if (nseq == 0) return GSR_OK;
@@ -427,23 +435,25 @@ int gsr_exclusive_scan_along_batch(const uint32_t *in, const uint32_t *idx, uint
     uint32_t *sums = (uint32_t *)workspace;
     const uint32_t nb = gsr_div_up(n, SCAN_TILE);
     const SegCounters cnt = {total, overflow_flag, counter_stride};
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb, nseq), dim3(SCAN_THREADS), 0, st, in, idx, n, sums, cnt);
+    if (!idx) gathered = nullptr;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb, nseq), dim3(SCAN_THREADS), 0, st, in, idx, n, sums, cnt, gathered);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1, nseq), dim3(1024), 0, st, sums, nb, cnt);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb, nseq), dim3(SCAN_THREADS), 0, st, in, idx, out, n, sums, out_seq);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb, nseq), dim3(SCAN_THREADS), 0, st, in, idx, out, n, sums, out_seq,
+                       (const uint32_t *)gathered);
     return gsr_check_launch("exclusive_scan");
 }
 
 int gsr_exclusive_scan_along(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t *total,
                              void *workspace, size_t workspace_bytes, void *stream, uint32_t *out_seq,
-                             uint32_t *overflow_flag)
+                             uint32_t *overflow_flag, uint32_t *gathered)
 {
-    return gsr_exclusive_scan_along_batch(in, idx, out, n, 1, total, overflow_flag, 0, workspace, workspace_bytes, stream, out_seq);
+    return gsr_exclusive_scan_along_batch(in, idx, out, n, 1, total, overflow_flag, 0, workspace, workspace_bytes, stream, out_seq, gathered);
 }
 
 extern "C" int gsr_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total, void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
-    return gsr_exclusive_scan_along(in, nullptr, out, n, total, workspace, workspace_bytes, stream, nullptr, nullptr);
+    return gsr_exclusive_scan_along(in, nullptr, out, n, total, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr);
 }
 
 // ---- exclusive scan without a workspace argument ---------------------------------------------
@@ -494,7 +504,7 @@ extern "C" int gsr_exclusive_scan_static(const uint32_t *in, uint32_t *out, uint
     if (int e = static_scan_scratch(&sums)) return e;
     // the kernels overwrite the block sums they read (one per 2048 elements), nothing has to start at zero
     return gsr_exclusive_scan_along(in, nullptr, out, n, total, sums, kStaticScanSums * sizeof(uint32_t), stream, nullptr,
-                                    nullptr);
+                                    nullptr, nullptr);
 }
 
 extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)
