@@ -145,6 +145,16 @@ __device__ inline const char *uniform_address(const char *p)
 // into an asm statement, so every asm below whose memory instruction takes such an address starts with them.
 #define kSgprReady "s_nop 4\n\t"
 
+// max(a, b) - b on the scalar unit.  Written as an expression the compiler makes it a saturating subtraction, which only
+// the vector ALU has, and brings the result back with v_readfirstlane: four vector instructions per touch of the
+// backward, 3 % of its loop.
+__device__ inline uint32_t scalar_sub_floor0(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("s_max_u32 %0, %1, %2\n\ts_sub_u32 %0, %0, %2" : "=&s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
+
 // Pulls the cache lines of records some entries further on into L2 with a vector load whose result
 // is never used (`lane_off` is 0 for half of the lanes and 64 for the others: a call touches two
 // neighbouring records, and one call per two entries touches every line of the stream; `off` is
@@ -630,13 +640,13 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             rec_wait(A, B);
             rec_request(stream_rec, back(2u), C);
             rec_request(stream_rec, back(3u), D);
-            l2_touch(stream_rec, max(off, (kTouchAheadBwd + 1) * 64u) - (kTouchAheadBwd + 1) * 64u, touch_off, sink);
+            l2_touch(stream_rec, scalar_sub_floor0(off, (kTouchAheadBwd + 1) * 64u), touch_off, sink);
             entry(A, k);
             entry(B, k);
             rec_wait(C, D);
             rec_request(stream_rec, back(4u), A);
             rec_request(stream_rec, back(5u), B);
-            l2_touch(stream_rec, max(off, (kTouchAheadBwd + 3) * 64u) - (kTouchAheadBwd + 3) * 64u, touch_off, sink);
+            l2_touch(stream_rec, scalar_sub_floor0(off, (kTouchAheadBwd + 3) * 64u), touch_off, sink);
             entry(C, k);
             entry(D, k);
             off = back(4u);
@@ -659,7 +669,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         rec_wait(A);
         rec_request(stream_rec, off - 64u, B);
         // the two lines below the one sixteen entries down (never below the start of the stream)
-        l2_touch(stream_rec, max(off, (kTouchAheadBwd + 1) * 64u) - (kTouchAheadBwd + 1) * 64u, touch_off, sink);
+        l2_touch(stream_rec, scalar_sub_floor0(off, (kTouchAheadBwd + 1) * 64u), touch_off, sink);
         entry(A, k);
         if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
         rec_wait(B);
