@@ -215,7 +215,7 @@ def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: 
     all-reduce, the colour gradients of the rank's views (``g_colors_local`` ``[V/world, N, 3]``, from
     ``render_views(..., g_colors=...)``) are gathered from all ranks into ``[V, N, 3]`` (rank r holds the
     views ``shard_views(V, world, r)``), and ``rebuild_sh(g_colors_all)`` writes ``bucket.sh`` from them
-    (``rasterizer.sh_grad_views``).  Per rank that is 11 N floats reduced and 3 N floats per view
+    (``rasterizer.sh_grad_views``, beside the all-reduce: the gather is issued first).  Per rank that is 11 N floats reduced and 3 N floats per view
     gathered in place of 59 N floats reduced; the sh gradient comes out identical on every rank and
     identical to a single-rank run.  ``force_collectives`` issues the two collectives for a single
     rank too (a rehearsal of the multi-rank path).  Returns the gathered colour gradients."""
@@ -232,12 +232,16 @@ def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: 
                          f"[{per_rank},N<={bucket.n},3]")
     n = g_colors_local.shape[1]
     if world == 1 and not (force_collectives and dist.is_available() and dist.is_initialized()):
-        g_all = g_colors_local
-    else:
-        dist.all_reduce(bucket.flat[:bucket.n * SMALL_FLOATS], op=dist.ReduceOp.SUM, group=group)
-        g_all = torch.empty((n_views, n, 3), dtype=g_colors_local.dtype, device=g_colors_local.device)
-        dist.all_gather_into_tensor(g_all, g_colors_local, group=group)
+        rebuild_sh(g_colors_local)
+        return g_colors_local
+    # The gather first, then the sum: the sh rebuild needs only the gathered colours and runs on the compute stream
+    # while the all-reduce is still on the wire (the two collectives are independent of each other).
+    g_all = torch.empty((n_views, n, 3), dtype=g_colors_local.dtype, device=g_colors_local.device)
+    gathered = dist.all_gather_into_tensor(g_all, g_colors_local, group=group, async_op=True)
+    summed = dist.all_reduce(bucket.flat[:bucket.n * SMALL_FLOATS], op=dist.ReduceOp.SUM, group=group, async_op=True)
+    gathered.wait()
     rebuild_sh(g_all)
+    summed.wait()
     return g_all
 
 
