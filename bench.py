@@ -120,6 +120,11 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.call(cmd, env=env))
+    # Standard output carries the ONE JSON line and nothing else: whatever native libraries print while the run lasts
+    # (RCCL announces its version on stdout when its communicator is created) goes to standard error instead.
+    sys.stdout.flush()
+    json_out = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world:
@@ -344,7 +349,8 @@ def main():
                 out["roofline"]["low_half_fraction"] = round(stats["executed"][1], 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cams, args)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_out, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
