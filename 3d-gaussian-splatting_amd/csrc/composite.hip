@@ -159,7 +159,7 @@ __device__ inline uint32_t scalar_sub_floor0(uint32_t a, uint32_t b)
 // is never used (`lane_off` is 0 for half of the lanes and 64 for the others: a call touches two
 // neighbouring records, and one call per two entries touches every line of the stream; `off` is
 // wave-uniform and added to the base on the scalar unit).  The scalar record loads then
-// hit L2 instead of waiting for HBM; a wave has only one record in flight, so HBM latency would
+// hit L2 instead of waiting for HBM; a wave has only one or two records in flight, so HBM latency would
 // otherwise bound the stream rate.  `sink` must stay live until the wave drains its vector loads
 // (l2_touch_drain), and the drain must come before any code that follows the loop: the compiler counts the
 // register as written when the load is ISSUED, so once the loop is left it may move the value elsewhere and
@@ -251,9 +251,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     const uint32_t touch_off = (threadIdx.x & 1) ? 0u : touch_back;
     float sink = 0.0f;
     if (w.begin < w.end) {
-        // Two record buffers, alternating: while one is blended the other is in flight.  All stream
-        // positions are 32-bit byte offsets (64 bytes per record).  Two entries per turn and ONE exit, an odd
-        // last entry after the loop: with an exit between the two entries as well, the compiler copied all
+        // Record buffers kept by hand: while some are blended the others are in flight.  All stream
+        // positions are 32-bit byte offsets (64 bytes per record).  Several entries per turn and ONE exit, the
+        // last entries after the loop: with an exit between two entries as well, the compiler copied all
         // sixteen accumulator registers twice per turn (a quarter of the loop's vector instructions).
         const uint32_t off_last = (w.end - 1) * 64u;
         const uint32_t off_stream_last = (w.total - 1) * 64u;   // the touches may run into the next lists
@@ -620,7 +620,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         if (!CHECK) U = fmaf(val, lanes.colour, U);
         put_record<MODE>(pairgrad, rec_off, lanes.full_off, val, kFullWriters, gs);
     };
-    // back to front, two record buffers alternating (see composite_fwd_kernel); k is only needed by
+    // back to front, record buffers kept by hand (see composite_fwd_kernel); k is only needed by
     // the checked variant
     const uint32_t off_first = w.begin * 64u;
     uint32_t off = (w.end - 1) * 64u;   // the caller guarantees a non-empty list
