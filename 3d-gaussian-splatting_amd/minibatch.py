@@ -234,14 +234,22 @@ def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: 
     if world == 1 and not (force_collectives and dist.is_available() and dist.is_initialized()):
         rebuild_sh(g_colors_local)
         return g_colors_local
-    # The gather first, then the sum: the sh rebuild needs only the gathered colours and runs on the compute stream
-    # while the all-reduce is still on the wire (the two collectives are independent of each other).
     g_all = torch.empty((n_views, n, 3), dtype=g_colors_local.dtype, device=g_colors_local.device)
-    gathered = dist.all_gather_into_tensor(g_all, g_colors_local, group=group, async_op=True)
-    summed = dist.all_reduce(bucket.flat[:bucket.n * SMALL_FLOATS], op=dist.ReduceOp.SUM, group=group, async_op=True)
-    gathered.wait()
-    rebuild_sh(g_all)
-    summed.wait()
+    small = bucket.flat[:bucket.n * SMALL_FLOATS]
+    if dist.get_backend(group) == "nccl":
+        # RCCL: the gather first, then the sum, both asynchronous: the sh rebuild needs only the gathered colours and
+        # runs on the compute stream while the all-reduce is still on the wire (the two are independent of each other)
+        gathered = dist.all_gather_into_tensor(g_all, g_colors_local, group=group, async_op=True)
+        summed = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        gathered.wait()
+        rebuild_sh(g_all)
+        summed.wait()
+    else:
+        # other backends (gloo in the tests, which stages device tensors through the host on streams of its own):
+        # one collective after the other - two of them in flight beside a kernel stalled a two-rank run on one GPU
+        dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group)
+        dist.all_gather_into_tensor(g_all, g_colors_local, group=group)
+        rebuild_sh(g_all)
     return g_all
 
 

@@ -18,12 +18,12 @@ def test_two_ranks_train_like_one(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    one = subprocess.run([sys.executable, tool, "--out", single], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    one = subprocess.run([sys.executable, tool, "--out", single], capture_output=True, text=True, timeout=150, cwd=ROOT, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
     port = 29700 + os.getpid() % 200
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), tool, "--out", ranks],
-                         capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+                         capture_output=True, text=True, timeout=150, cwd=ROOT, env=env)
     assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-1500:])
     cmp_ = subprocess.run([sys.executable, tool, "--compare", single, ranks + "0.npz", ranks + "1.npz"], capture_output=True,
                           text=True, timeout=100, cwd=ROOT, env=env)

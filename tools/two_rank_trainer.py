@@ -39,7 +39,7 @@ class RingLoader:
         return self.cams[self.k], self.targets[self.k]
 
 
-def run(out, steps, views, staged=False, trace=False, sync_before=False, watchdog=240):
+def run(out, steps, views, staged=False, trace=False, sync_before=False, watchdog=90):
     import torch.distributed as dist
     import gsplat_amd  # noqa: F401
     from gsplat_amd.camera import Camera
@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--staged", action="store_true", help="run the collectives on host copies of the tensors")
     ap.add_argument("--trace", action="store_true", help="announce every collective before and after")
     ap.add_argument("--sync-before", action="store_true", help="synchronise the stream before each collective")
-    ap.add_argument("--watchdog", type=int, default=240, help="seconds until a stuck run dumps its Python stacks and exits")
+    ap.add_argument("--watchdog", type=int, default=90, help="seconds until a stuck run dumps its Python stacks and exits")
     args = ap.parse_args()
     if args.compare:
         compare(*args.compare)
