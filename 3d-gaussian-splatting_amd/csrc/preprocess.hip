@@ -304,8 +304,9 @@ __device__ inline bool project_to_view(const ViewK &v, int i, const float p[3], 
     }
     out.mask[i] = vis ? 1 : 0;
     out.depth_key[i] = key;
-    out.pos2d[3 * i] = px; out.pos2d[3 * i + 1] = py; out.pos2d[3 * i + 2] = pz;
-    reinterpret_cast<float4 *>(out.cov2d)[i] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+    // Nothing downstream reads these two: they exist for the caller (uniform branches, a kernel argument).
+    if (out.pos2d) { out.pos2d[3 * i] = px; out.pos2d[3 * i + 1] = py; out.pos2d[3 * i + 2] = pz; }
+    if (out.cov2d) reinterpret_cast<float4 *>(out.cov2d)[i] = make_float4(cv[0], cv[1], cv[2], cv[3]);
     out.radius[i] = rad;
     reinterpret_cast<int4 *>(out.bbox)[i] = make_int4(bx[0], bx[1], bx[2], bx[3]);
     out.ntiles[i] = nt;
@@ -381,7 +382,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_views_kernel(
         bool vis = false, singular = false;
         if (i < n) {
             const size_t at = (size_t)k * (size_t)n;
-            const FwdOut out = {out0.mask + at, out0.depth_key + at, out0.pos2d + 3 * at, out0.cov2d + 4 * at, out0.radius + at,
+            const FwdOut out = {out0.mask + at, out0.depth_key + at, out0.pos2d ? out0.pos2d + 3 * at : nullptr,
+                                out0.cov2d ? out0.cov2d + 4 * at : nullptr, out0.radius + at,
                                 out0.bbox + 4 * at, out0.ntiles + at, out0.rec + GSR_REC_FLOATS * at};
             vis = project_to_view(views.v[k], i, p, g, opac_raw, sh, nullptr, co, co_loaded, out, singular);
         }
@@ -854,8 +856,8 @@ extern "C" int gsr_preprocess_fwd_views(const gsr_view *views_host, uint32_t num
         }
     }
     for (uint32_t k = num_views; k < (uint32_t)kMaxFwdViews; ++k) views.v[k] = views.v[0];
-    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !mask || !depth_key || !pos2d || !cov2d ||
-        !radius || !bbox || !ntiles || !rec || !counters) {
+    if (!coords || !scale_raw || !rot_raw || !opac_raw || !sh || !mask || !depth_key || !radius || !bbox || !ntiles ||
+        !rec || !counters) {
         gsr_set_error("gsr_preprocess_fwd_views: null pointer");
         return GSR_ERR_ARG;
     }

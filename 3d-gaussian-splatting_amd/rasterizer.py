@@ -185,17 +185,18 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
     return st
 
 
-def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views) -> list:
+def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, projection: bool = False) -> list:
     """``forward_begin`` for several views of the same Gaussians (at most ``_lib.MAX_VIEWS`` per call; more are
     taken in groups): ONE pass over the parameters for stage 1 of all of them, ONE set of launches for their depth
     orders and ONE read-back of all counters.  Returns one ``RenderState`` per view, the same - bit for bit - as
-    ``forward_begin`` leaves (their arrays are slices of arrays that hold all views)."""
+    ``forward_begin`` leaves (their arrays are slices of arrays that hold all views), except that ``pos2d`` and
+    ``cov2d`` - which nothing after stage 1 reads - are only written, and kept, with ``projection=True``."""
     lib = _lib.load()
     views = list(views)
     if len(views) > _lib.MAX_VIEWS:
         out = []
         for k in range(0, len(views), _lib.MAX_VIEWS):
-            out += forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views[k:k + _lib.MAX_VIEWS])
+            out += forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views[k:k + _lib.MAX_VIEWS], projection)
         return out
     if len(views) == 1:
         return [forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, None, views[0])]
@@ -216,8 +217,8 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views) -> list
                                    for v in views])
     mask = torch.empty(nv, n, dtype=torch.uint8, device=dev)
     depth_key = torch.empty(nv, n, **i32)
-    pos2d = torch.empty(nv, n, 3, **f32)
-    cov2d = torch.empty(nv, n, 4, **f32)
+    pos2d = torch.empty(nv, n, 3, **f32) if projection else None
+    cov2d = torch.empty(nv, n, 4, **f32) if projection else None
     radius = torch.empty(nv, n, **f32)
     bbox = torch.empty(nv, n, 4, **i32)
     ntiles = torch.empty(nv, n, **i32)
@@ -247,7 +248,8 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views) -> list
     for k in range(nv):
         st = RenderState()
         st.view, st.n, st.cview = views[k], n, cviews[k]
-        st.mask_u8, st.pos2d, st.cov2d, st.radius_full = mask[k], pos2d[k], cov2d[k], radius[k]
+        st.mask_u8, st.radius_full = mask[k], radius[k]
+        st.pos2d, st.cov2d = (pos2d[k], cov2d[k]) if projection else (None, None)
         st.bbox, st.ntiles, st.rec = bbox[k], ntiles[k], rec[k]
         st.order, st.slot_base, st.slot_seq = order[k], slot_base[k], slot_seq[k]
         st._counters, st._host, st._ready = counters, host[k], ready

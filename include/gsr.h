@@ -100,7 +100,8 @@ int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const flo
  * 99-108) are evaluated once; per view the results equal gsr_preprocess_fwd's bit for bit.  views_host: the
  * views (same n and sh degree).  Every output array holds the views one after the other: view k's rows
  * start k * n rows in (mask[num_views*N], pos2d[num_views*N,3], ...); counters[num_views].  screen_coords
- * are taken as zeros. */
+ * are taken as zeros.  pos2d and cov2d may each be NULL: no later call reads them, and a caller that does not
+ * either saves their 28 bytes per Gaussian and view. */
 int gsr_preprocess_fwd_views(const gsr_view *views_host, uint32_t num_views, const float *coords,
                              const float *scale_raw, const float *rot_raw, const float *opac_raw, const float *sh,
                              uint8_t *mask, uint32_t *depth_key, float *pos2d, float *cov2d, float *radius,
