@@ -208,6 +208,13 @@ def can_factor(n_views: int, world_size: int) -> bool:
     return world_size >= 1 and n_views % world_size == 0
 
 
+def factored_moves_less(n_views: int) -> bool:
+    """Whether the factored exchange moves fewer bytes than summing the sh gradient itself: each rank receives
+    3 floats per Gaussian and view of the step from the gather, against about 2 x 48 per Gaussian that a ring
+    all-reduce of the sh gradient sends and receives - the gather wins below 32 views per step."""
+    return 3 * n_views < 2 * 48
+
+
 def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: int, rebuild_sh: Callable, group=None,
                      force_collectives: bool = False):
     """Gradient exchange of one step between ranks that hold the same parameters, without moving the

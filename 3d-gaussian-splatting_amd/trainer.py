@@ -166,7 +166,7 @@ class MinibatchTrainer(Trainer):
         import torch.distributed as dist
         from . import densify as D
         from .loss import loss_and_grad
-        from .minibatch import can_factor, reduce_densify_stats, reduce_gradients, render_views, shard_views
+        from .minibatch import can_factor, factored_moves_less, reduce_densify_stats, reduce_gradients, render_views, shard_views
         from .rasterizer import ViewSpec, sh_grad_views
         model, V = self.model, self.views_per_step
         world, rank = self._ranks()
@@ -179,7 +179,7 @@ class MinibatchTrainer(Trainer):
             params = [p.data[:size] for p in (model._coords, model._scale, model._rotation, model._opacity, model._sh)]
             bucket = self._gradient_bucket(size)
             grads = tuple(v[:size] for v in bucket.views)
-            factored = world > 1 and can_factor(V, world)
+            factored = world > 1 and can_factor(V, world) and factored_moves_less(V)
             g_colors = torch.empty((len(mine), size, 3), dtype=torch.float32, device=dev) if factored else None
             losses = []
 

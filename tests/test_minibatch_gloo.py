@@ -136,8 +136,9 @@ def test_two_rank_factored_exchange_moves_the_right_blocks(tmp_path):
 
 def test_factored_exchange_needs_an_even_split():
     import gsplat_amd  # noqa: F401
-    from gsplat_amd.minibatch import GradBucket, can_factor, reduce_gradients
+    from gsplat_amd.minibatch import GradBucket, can_factor, factored_moves_less, reduce_gradients
     assert can_factor(8, 1) and can_factor(8, 8) and not can_factor(8, 3)
+    assert factored_moves_less(8) and factored_moves_less(31) and not factored_moves_less(32)
     with pytest.raises(ValueError):
         reduce_gradients(GradBucket(5, "cpu"), torch.zeros(2, 6, 3), 2, lambda g: None)    # more Gaussians than bucket rows
     # a bucket of capacity rows takes the colour gradients of fewer live Gaussians
