@@ -210,6 +210,20 @@ __device__ inline void load_sh(const float *sh, int i, int K, float co[3][16])
 }
 
 // Where stage 1 leaves what it computes for one view (every array is indexed by Gaussian).
+// Sum of one value per lane over the wave, all 64 lanes active (every lane gets it): four adds with lane swizzles
+// inside the rows of 16 (neighbour, pair, mirrored half row, mirrored row), then the four row sums meet on the scalar unit.
+template <int CTRL>
+__device__ inline uint32_t dpp_add_u32(uint32_t x)
+{
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+}
+__device__ inline uint32_t wave_sum_u32(uint32_t x)
+{
+    x = dpp_add_u32<0x140>(dpp_add_u32<0x141>(dpp_add_u32<0x4E>(dpp_add_u32<0xB1>(x))));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 0) + (uint32_t)__builtin_amdgcn_readlane((int)x, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)x, 32) + (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+}
+
 struct FwdOut {
     uint8_t *mask;
     uint32_t *depth_key;
@@ -224,7 +238,7 @@ struct FwdOut {
 // coefficients, loaded on the first view that sees it (`co_loaded`).  Returns whether the Gaussian is visible.
 __device__ inline bool project_to_view(const ViewK &v, int i, const float p[3], Geom &g, const float *__restrict__ opac_raw,
                                        const float *__restrict__ sh, const float *__restrict__ screen_coords, float (&co)[3][16],
-                                       bool &co_loaded, const FwdOut &out, bool &singular)
+                                       bool &co_loaded, const FwdOut &out, bool &singular, uint32_t &tiles)
 {
     geometry_view(v.w2m, v.proj, p, g);
     // Utils/Camera.py:106-108 (NaN compares false: culled)
@@ -310,6 +324,7 @@ __device__ inline bool project_to_view(const ViewK &v, int i, const float p[3], 
     out.radius[i] = rad;
     reinterpret_cast<int4 *>(out.bbox)[i] = make_int4(bx[0], bx[1], bx[2], bx[3]);
     out.ntiles[i] = nt;
+    tiles = nt;
     float4 *dst = reinterpret_cast<float4 *>(out.rec + (size_t)i * GSR_REC_FLOATS);
     dst[0] = r0; dst[1] = r1; dst[2] = r2;
     return vis;
@@ -323,6 +338,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool vis = false;
     bool singular = false;
+    uint32_t tiles = 0;
     if (i < v.n) {
         const float p[3] = {coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
         const float sr[3] = {scale_raw[3 * i], scale_raw[3 * i + 1], scale_raw[3 * i + 2]};
@@ -332,18 +348,26 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         geometry_model(sr, qr, g);
         float co[3][16];
         bool co_loaded = false;
-        vis = project_to_view(v, i, p, g, opac_raw, sh, screen_coords, co, co_loaded, out, singular);
+        vis = project_to_view(v, i, p, g, opac_raw, sh, screen_coords, co, co_loaded, out, singular, tiles);
     }
     // One atomic per BLOCK for the visible count: atomics of all waves on one address serialise at
     // about 7 ns each, which at one per wave (15.6 k waves for a million Gaussians) costs more than the
     // rest of the kernel.
-    __shared__ uint32_t wave_visible[4];
+    // The same for the number of (tile, Gaussian) pairs of the view, the sum of the tile counts: it does not
+    // depend on the depth order, so the host can read it - and size the per-pair buffers - while the sort runs.
+    __shared__ uint32_t wave_visible[4], wave_tiles[4];
     const unsigned long long bal = __ballot(vis);
-    if ((threadIdx.x & 63) == 0) wave_visible[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    const uint32_t wave_sum = wave_sum_u32(tiles);      // (at most 64 x 2^13 per wave)
+    if ((threadIdx.x & 63) == 0) {
+        wave_visible[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+        wave_tiles[threadIdx.x >> 6] = wave_sum;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t c = wave_visible[0] + wave_visible[1] + wave_visible[2] + wave_visible[3];
         if (c) atomicAdd(&counters->num_visible, c);
+        const uint32_t t = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(counters->pairs_wide), (unsigned long long)t);
     }
     if (singular) atomicOr(&counters->error, 1u);
 }
@@ -357,15 +381,16 @@ struct FwdViews {
     int nv;
 };
 
-__global__ __launch_bounds__(256) void preprocess_fwd_views_kernel(
+constexpr int kFwdViewsThreads = 512;
+__global__ __launch_bounds__(kFwdViewsThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void preprocess_fwd_views_kernel(
     FwdViews views, const float *__restrict__ coords, const float *__restrict__ scale_raw,
     const float *__restrict__ rot_raw, const float *__restrict__ opac_raw, const float *__restrict__ sh, FwdOut out0,
     gsr_counters *__restrict__ counters)
 {
     const int n = views.v[0].n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ uint32_t visible[kMaxFwdViews];
-    if (threadIdx.x < kMaxFwdViews) visible[threadIdx.x] = 0;
+    __shared__ uint32_t visible[kMaxFwdViews], tiles_of[kMaxFwdViews];
+    if (threadIdx.x < kMaxFwdViews) visible[threadIdx.x] = tiles_of[threadIdx.x] = 0;
     __syncthreads();
     float p[3] = {0.f, 0.f, 0.f};
     Geom g;
@@ -380,19 +405,28 @@ __global__ __launch_bounds__(256) void preprocess_fwd_views_kernel(
     }
     for (int k = 0; k < views.nv; ++k) {
         bool vis = false, singular = false;
+        uint32_t tiles = 0;
         if (i < n) {
             const size_t at = (size_t)k * (size_t)n;
             const FwdOut out = {out0.mask + at, out0.depth_key + at, out0.pos2d ? out0.pos2d + 3 * at : nullptr,
                                 out0.cov2d ? out0.cov2d + 4 * at : nullptr, out0.radius + at,
                                 out0.bbox + 4 * at, out0.ntiles + at, out0.rec + GSR_REC_FLOATS * at};
-            vis = project_to_view(views.v[k], i, p, g, opac_raw, sh, nullptr, co, co_loaded, out, singular);
+            vis = project_to_view(views.v[k], i, p, g, opac_raw, sh, nullptr, co, co_loaded, out, singular, tiles);
         }
         const unsigned long long bal = __ballot(vis);
-        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&visible[k], (uint32_t)__popcll(bal));
+        const uint32_t wave_sum = wave_sum_u32(tiles);
+        if ((threadIdx.x & 63) == 0 && bal) {
+            atomicAdd(&visible[k], (uint32_t)__popcll(bal));
+            atomicAdd(&tiles_of[k], wave_sum);
+        }
         if (singular) atomicOr(&counters[k].error, 1u);
     }
     __syncthreads();
-    if (threadIdx.x < views.nv && visible[threadIdx.x]) atomicAdd(&counters[threadIdx.x].num_visible, visible[threadIdx.x]);
+    if (threadIdx.x < views.nv && visible[threadIdx.x]) {
+        atomicAdd(&counters[threadIdx.x].num_visible, visible[threadIdx.x]);
+        if (tiles_of[threadIdx.x])
+            atomicAdd(reinterpret_cast<unsigned long long *>(counters[threadIdx.x].pairs_wide), (unsigned long long)tiles_of[threadIdx.x]);
+    }
 }
 
 template <bool ACC>
@@ -864,7 +898,7 @@ extern "C" int gsr_preprocess_fwd_views(const gsr_view *views_host, uint32_t num
     const int n = views.v[0].n;
     if (n == 0) return GSR_OK;
     const FwdOut out = {mask, depth_key, pos2d, cov2d, radius, bbox, ntiles, rec};
-    hipLaunchKernelGGL(preprocess_fwd_views_kernel, dim3(gsr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, views,
+    hipLaunchKernelGGL(preprocess_fwd_views_kernel, dim3(gsr_div_up(n, kFwdViewsThreads)), dim3(kFwdViewsThreads), 0, (hipStream_t)stream, views,
                        coords, scale_raw, rot_raw, opac_raw, sh, out, counters);
     return gsr_check_launch("preprocess_fwd_views");
 }

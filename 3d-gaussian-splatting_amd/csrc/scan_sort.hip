@@ -306,13 +306,19 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t wbase = tile_base + wave * (SORT_ITEMS * 64);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t key[SORT_ITEMS], rank[SORT_ITEMS];
+    V word[WORDS ? SORT_ITEMS : 1];
     volatile uint32_t *mycnt = cnt[wave];
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const uint32_t i = wbase + it * 64 + lane;
         const bool valid = i < n;
         // (WORDS: the 32 bits of the word from its digit on; the code below then finds the digit at bit 0)
-        key[it] = valid ? (WORDS ? word_key(vals_in[i], word_shift) : keys_in[i]) : 0xFFFFFFFFu;
+        if (WORDS) {
+            word[it] = valid ? vals_in[i] : (V)0;
+            key[it] = valid ? word_key(word[it], word_shift) : 0xFFFFFFFFu;
+        } else {
+            key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        }
         const uint32_t d = (key[it] >> shift) & mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -359,6 +365,26 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
                 const uint32_t pos = cnt[wave][d] + rank[it];
                 keys_out[pos] = key[it];
                 vals_out[pos] = vals_in[i];
+            }
+        }
+        return;
+    }
+    if (WORDS) {
+        // the words themselves into digit order (their digit is read back from the staged word)
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t i = wbase + it * 64 + lane;
+            const uint32_t d = key[it] & mask;
+            if (i < n) stage[cnt[wave][d] + rank[it]] = word[it];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t l = it * SORT_THREADS + threadIdx.x;
+            if (l < tile_count) {
+                const V word = stage[l];
+                const uint32_t d = word_key(word, word_shift) & mask;
+                vals_out[gbase[d] + (l - lstart[d])] = word;
             }
         }
         return;

@@ -81,6 +81,14 @@ def _front_stream(dev):
     return _front_streams[key]
 
 
+def _front_follows(front, cur):
+    """Orders whatever is enqueued on the side stream from now on after everything enqueued on ``cur`` so far."""
+    if front is not cur:
+        done = torch.cuda.Event()
+        done.record(cur)
+        front.wait_event(done)
+
+
 def reserve_streams(device=None):
     """Creates the two side streams of the pipelined minibatch (front part of the next views, counter read-back)
     and runs a trivial operation on each, which binds them to hardware queues of their own.
@@ -127,6 +135,12 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
         start = torch.cuda.Event()
         start.record(cur)
         front.wait_event(start)          # the parameters may have been written on the current stream
+    # The buffers of a view are allocated while the side stream is current and read by kernels on the current stream.
+    # They are NOT marked as in use there (Tensor.record_stream): the caching allocator would record an event per
+    # buffer when the states are dropped - over a hundred markers queued behind the step's last kernel, 0.2 ms in
+    # which the GPU ran nothing.  Instead the side stream is made to wait, below, for everything this call enqueues
+    # on the current stream: memory that the allocator hands out again for the side stream is then only touched after
+    # the kernels that read it here have finished.
     begun: List = []
 
     def begin(i):
@@ -178,13 +192,13 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
             continue
         if front is not cur:
             cur.wait_event(ready)
-            R.share_with_stream(st, cur)
         R.forward_composite(st)
         if cotangent is None:
             continue
         live.append(st)
         gsums.append(R.backward_records(st, cotangent(i, st)))
     if cotangent is None:
+        _front_follows(front, cur)
         return states, None, []
     cols = None
     if g_colors is not None:
@@ -193,6 +207,7 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
             if not st.num_visible:
                 g_colors[i].zero_()
     grads, g_screens = R.backward_views(live, gsums, *params, grads=grads, accumulate=accumulate, g_colors=cols)
+    _front_follows(front, cur)
     return states, grads, g_screens
 
 

@@ -162,15 +162,9 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
                                       _ptr(screen_coords), _ptr(st.mask_u8), _ptr(depth_key), _ptr(st.pos2d),
                                       _ptr(st.cov2d), _ptr(st.radius_full), _ptr(st.bbox), _ptr(st.ntiles),
                                       _ptr(st.rec), _ptr(counters), stream)
-    st.order = torch.empty(n, **i32)
-    st.slot_base = torch.empty(n, **i32)
-    st.slot_seq = torch.empty(n + 1, **i32)
-    ws_bytes = int(lib.gsr_bin_offsets_workspace_bytes(n))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _call("gsr_bin_offsets", lib.gsr_bin_offsets, _ptr(depth_key), _ptr(st.ntiles), n, _ptr(st.order), _ptr(st.slot_base),
-                                   _ptr(st.slot_seq), _ptr(counters), _ptr(ws), ws_bytes, stream)
-    # read the counters back on a side stream: the copy is ordered after bin_offsets only, not after
-    # whatever the caller enqueues on the main stream next
+    # Read the counters back on a side stream, right behind stage 1: the number of visible Gaussians, the error word
+    # and the number of pairs (stage 1 sums the tile counts) are final there, so the copy, the host's wait for it and
+    # the sizing of the per-pair buffers run beside the depth sort that is enqueued next.
     main = torch.cuda.current_stream(dev)
     side = _copy_stream(dev)
     done = torch.cuda.Event()
@@ -182,6 +176,13 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
         side.wait_event(done)
         st._host.copy_(counters, non_blocking=True)
         st._ready.record(side)
+    st.order = torch.empty(n, **i32)
+    st.slot_base = torch.empty(n, **i32)
+    st.slot_seq = torch.empty(n + 1, **i32)
+    ws_bytes = int(lib.gsr_bin_offsets_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _call("gsr_bin_offsets", lib.gsr_bin_offsets, _ptr(depth_key), _ptr(st.ntiles), n, _ptr(st.order), _ptr(st.slot_base),
+                                   _ptr(st.slot_seq), _ptr(counters), _ptr(ws), ws_bytes, stream)
     return st
 
 
@@ -227,6 +228,16 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, project
     _call("gsr_preprocess_fwd_views", lib.gsr_preprocess_fwd_views, cviews, nv, _ptr(coords), _ptr(scale_raw), _ptr(rot_raw),
           _ptr(opac_raw), _ptr(sh), _ptr(mask), _ptr(depth_key), _ptr(pos2d), _ptr(cov2d), _ptr(radius), _ptr(bbox),
           _ptr(ntiles), _ptr(rec), _ptr(counters), stream)
+    main = torch.cuda.current_stream(dev)
+    side = _copy_stream(dev)
+    done = torch.cuda.Event()
+    done.record(main)
+    host = torch.empty(nv, 8, dtype=torch.int32, pin_memory=True)
+    ready = torch.cuda.Event()
+    with torch.cuda.stream(side):        # (the counters are final after stage 1: see forward_begin)
+        side.wait_event(done)
+        host.copy_(counters, non_blocking=True)
+        ready.record(side)
     order = torch.empty(nv, n, **i32)
     slot_base = torch.empty(nv, n, **i32)
     slot_seq = torch.empty(nv, n + 1, **i32)
@@ -234,16 +245,6 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, project
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _call("gsr_bin_offsets_views", lib.gsr_bin_offsets_views, _ptr(depth_key), _ptr(ntiles), n, nv, _ptr(order), _ptr(slot_base),
           _ptr(slot_seq), _ptr(counters), _ptr(ws), ws_bytes, stream)
-    main = torch.cuda.current_stream(dev)
-    side = _copy_stream(dev)
-    done = torch.cuda.Event()
-    done.record(main)
-    host = torch.empty(nv, 8, dtype=torch.int32, pin_memory=True)
-    ready = torch.cuda.Event()
-    with torch.cuda.stream(side):
-        side.wait_event(done)
-        host.copy_(counters, non_blocking=True)
-        ready.record(side)
     states = []
     for k in range(nv):
         st = RenderState()
@@ -298,7 +299,13 @@ def read_counters(st: RenderState):
         return
     st._ready.synchronize()
     host = st._host
-    st.num_visible, st.num_pairs, err = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2])
+    words = host.tolist()                  # (one conversion: indexing the pinned tensor word by word costs 3 us each)
+    # gsr_counters: num_visible, num_pairs (written later, by the scan), error, -, the 64-bit pair total of stage 1
+    st.num_visible, err = words[0], words[2]
+    pairs = (words[4] & 0xFFFFFFFF) | ((words[5] & 0xFFFFFFFF) << 32)
+    st.num_pairs = pairs & 0xFFFFFFFF
+    if pairs >> 32:
+        err |= 2
     if host._base is None:
         _pinned_pool.append(host)          # (a row of the buffer that several views share is not recycled)
     st._host = st._counters = st._ready = None
@@ -382,17 +389,6 @@ def forward_composite(st: RenderState) -> RenderState:
 def forward_finish(st: RenderState) -> RenderState:
     """``forward_lists`` + ``forward_composite`` on the current stream."""
     return forward_composite(forward_lists(st))
-
-
-def share_with_stream(st: RenderState, stream):
-    """Marks the buffers of a view that were allocated while another stream was current as in use on
-    ``stream`` too, so that the caching allocator does not hand them out again before the work
-    enqueued there has finished."""
-    for name in ("mask_u8", "ntiles", "slot_base", "slot_seq", "tile_offsets", "tile_order", "stream_rec", "sorted_gauss", "rec", "bbox",
-                 "order", "pos2d", "cov2d", "radius_full"):
-        t = getattr(st, name)
-        if t is not None:
-            t.record_stream(stream)
 
 
 def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec) -> RenderState:

@@ -43,7 +43,7 @@ typedef struct gsr_view {
     float cam_pos[3];    /* cam.transform.position */
 } gsr_view;
 
-/* Device-side counters written by gsr_preprocess_fwd / gsr_bin_offsets (8 x u32). */
+/* Device-side counters written by gsr_preprocess_fwd / gsr_bin_offsets (8 x u32; 8-byte aligned). */
 typedef struct gsr_counters {
     uint32_t num_visible; /* M = mask.sum() */
     uint32_t num_pairs;   /* I = sum over tiles of list length */
@@ -53,7 +53,12 @@ typedef struct gsr_counters {
                              32 bits - num_pairs and the slots are then meaningless and the caller must
                              stop (the reference would build lists of that total length,
                              GaussianRenderer.py:89-97) */
-    uint32_t reserved[5];
+    uint32_t reserved0;
+    uint32_t pairs_wide[2]; /* written by gsr_preprocess_fwd[_views] (8-byte aligned, low word first): the 64-bit sum
+                             of the view's tile counts = the number of pairs gsr_bin_offsets will report, known
+                             before the depth order exists.  A caller that sizes its per-pair buffers on the host
+                             reads it back while the sort runs; a sum of 2^32 or more is the error of bit 1 above */
+    uint32_t reserved[2];
 } gsr_counters;
 
 /* Per-Gaussian splat record produced by stage 1 and consumed by the compositing kernels. */
@@ -86,7 +91,7 @@ int gsr_version(void);
  * (opacity, SH colour, radius), Utils/Screen.py:30-36 (integer bounding boxes).
  * Outputs (N-indexed): mask u8, depth_key u32 (bits of the NDC depth, 0xFFFFFFFF when culled),
  * pos2d[N,3], cov2d[N,4], radius[N], bbox[N,4] i32 (xmin,ymin,xmax,ymax), ntiles[N] u32,
- * rec[N,12].  counters->num_visible and ->error are accumulated (zero them first).
+ * rec[N,12].  counters->num_visible, ->pairs_wide and ->error are accumulated (zero them first).
  * screen_coords may be NULL (= zeros, GaussianRenderer.py:64). */
 int gsr_preprocess_fwd(const gsr_view *view_host, const float *coords, const float *scale_raw,
                        const float *rot_raw, const float *opac_raw, const float *sh,

@@ -158,3 +158,20 @@ def test_batched_front_with_a_view_that_sees_nothing():
     assert len(s_mixed) == len(s_seen) == 2
     for a, b in zip(list(g_mixed) + list(s_mixed), list(g_seen) + list(s_seen)):
         _same(a, b, "gradients with and without the blind view")
+
+
+@pytest.mark.parametrize("n,w,h,deg,nviews", [(3000, 200, 120, 3, 1), (70_001, 640, 360, 2, 5), (5, 64, 48, 0, 2)])
+def test_stage_1_counts_the_pairs_the_scan_will_report(n, w, h, deg, nviews):
+    """The pair total that stage 1 accumulates (gsr_counters.pairs_wide, what the host sizes its buffers from) equals
+    the total of the scan along the depth order and the sum of the tile counts, per view, in both entry points."""
+    from gsplat_amd import rasterizer as R
+    dev, params, views = _scene(n, w, h, deg, nviews)
+    begun = R.forward_begin_views(*params, views) if nviews > 1 else [R.forward_begin(*params, None, views[0])]
+    device_counters = [st._counters for st in begun]
+    torch.cuda.synchronize()
+    for k, st in enumerate(begun):
+        words = device_counters[k].cpu().numpy().reshape(-1, 8)[k if nviews > 1 else 0].astype(np.int64) & 0xFFFFFFFF
+        R.read_counters(st)
+        total = int(st.ntiles.cpu().numpy().astype(np.int64).sum())
+        assert (int(words[1]), int(words[4]), int(words[5])) == (total, total, 0), k
+        assert st.num_pairs == total and st.num_visible == int(st.mask_u8.sum())

@@ -11,6 +11,8 @@ cd "$root"
 timeout -k 10 240 python bench.py > $out/bench_line.json 2> $out/bench_line.err
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline > "$root/$out/bench_line_profiled.json" 2> "$root/$out/prof.err")
 cp $out/prof/*/*kernel_stats.csv $out/bench_kernel_stats.csv
+python tools/trace_timeline.py $out/prof > $out/step_timeline.txt
+python tools/trace_gaps.py $out/prof 24 >> $out/step_timeline.txt
 python tools/kstats.py $out/prof 12
 bash tools/traffic_passes.sh $out/traffic
 python tools/traffic_json.py $out/traffic $out/traffic.json
