@@ -58,6 +58,20 @@ struct SegCounters {
     uint32_t stride;           // words between the records of two sequences
 };
 
+// Which sequence and which of its blocks a workgroup of a (blocks, sequences) grid works on.  Consecutive workgroups go
+// to consecutive XCDs (8, each with an L2 of its own), so the sequences are interleaved over the workgroup numbers:
+// with eight sequences - the views of a step - every XCD gathers from and scatters into the arrays of ONE view, which
+// its L2 holds, instead of all of them.
+struct SeqBlock {
+    uint32_t seq, block;
+};
+__device__ inline SeqBlock seq_block()
+{
+    if (gridDim.y == 1) return {0u, blockIdx.x};
+    const uint32_t linear = blockIdx.y * gridDim.x + blockIdx.x;
+    return {linear % gridDim.y, linear / gridDim.y};
+}
+
 // With idx != null element i of the sequence is in[idx[i]] and its result goes to out[idx[i]]
 // (a scan along a permutation; in and out may then not alias).
 // gathered (may be null, only with idx): the elements in sequence order, gathered[i] = in[idx[i]], written here so
@@ -69,12 +83,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
     __shared__ unsigned long long wide;
-    in += (size_t)blockIdx.y * n;
-    if (idx) idx += (size_t)blockIdx.y * n;
-    if (gathered) gathered += (size_t)blockIdx.y * n;
-    block_sums += (size_t)blockIdx.y * gridDim.x;
-    uint32_t *overflow_flag = cnt.overflow_flag ? cnt.overflow_flag + (size_t)blockIdx.y * cnt.stride : nullptr;
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    const SeqBlock wg = seq_block();
+    in += (size_t)wg.seq * n;
+    if (idx) idx += (size_t)wg.seq * n;
+    if (gathered) gathered += (size_t)wg.seq * n;
+    block_sums += (size_t)wg.seq * gridDim.x;
+    uint32_t *overflow_flag = cnt.overflow_flag ? cnt.overflow_flag + (size_t)wg.seq * cnt.stride : nullptr;
+    const uint32_t base = wg.block * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
     unsigned long long s64 = 0;
 #pragma unroll
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
     }
     uint32_t total;
     block_exclusive_scan(s, lds, total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) block_sums[wg.block] = total;
 }
 
 // One block: exclusive scan of block_sums[0..nb) in place, total to *total_out (may be null).
@@ -142,13 +157,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
                                                                   const uint32_t *__restrict__ gathered)
 {
     __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
-    if (gathered) gathered += (size_t)blockIdx.y * n;
-    in += (size_t)blockIdx.y * n;
-    out += (size_t)blockIdx.y * n;
-    if (idx) idx += (size_t)blockIdx.y * n;
-    if (out_seq) out_seq += (size_t)blockIdx.y * (n + 1);
-    block_sums += (size_t)blockIdx.y * gridDim.x;
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    const SeqBlock wg = seq_block();
+    if (gathered) gathered += (size_t)wg.seq * n;
+    in += (size_t)wg.seq * n;
+    out += (size_t)wg.seq * n;
+    if (idx) idx += (size_t)wg.seq * n;
+    if (out_seq) out_seq += (size_t)wg.seq * (n + 1);
+    block_sums += (size_t)wg.seq * gridDim.x;
+    const uint32_t base = wg.block * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS], at[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
         s += v[k];
     }
     uint32_t total;
-    uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan(s, lds, total);
+    uint32_t run = block_sums[wg.block] + block_exclusive_scan(s, lds, total);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         if (base + k < n) {
@@ -199,27 +215,29 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const K *__res
                                                                   uint32_t *__restrict__ hist, SortSegs segs)
 {
     __shared__ uint32_t h[RADIX_SIZE];
+    // (equally long sequences are interleaved over the workgroup numbers, see seq_block)
+    const SeqBlock wg = segs.count ? SeqBlock{blockIdx.y, blockIdx.x} : seq_block();
     if (segs.count) {
-        n = seg_pick(segs.n, blockIdx.y);
-        nb = seg_pick(segs.nb, blockIdx.y);
-        if (blockIdx.x >= nb) return;
-        keys += seg_pick(segs.base, blockIdx.y);
-        hist += seg_pick(segs.hbase, blockIdx.y);
+        n = seg_pick(segs.n, wg.seq);
+        nb = seg_pick(segs.nb, wg.seq);
+        if (wg.block >= nb) return;
+        keys += seg_pick(segs.base, wg.seq);
+        hist += seg_pick(segs.hbase, wg.seq);
     } else {
         // (sequence blockIdx.y of a batch of equally long ones: y * n keys and y * 256 * nb counts further on)
-        keys += (size_t)blockIdx.y * n;
-        hist += (size_t)blockIdx.y * RADIX_SIZE * nb;
+        keys += (size_t)wg.seq * n;
+        hist += (size_t)wg.seq * RADIX_SIZE * nb;
     }
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * SORT_TILE;
+    const uint32_t base = wg.block * SORT_TILE;
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const uint32_t i = base + it * SORT_THREADS + threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+    hist[threadIdx.x * nb + wg.block] = h[threadIdx.x];
 }
 
 // Turns the per-block digit counts into per-block offsets inside each digit: block d of this kernel
@@ -274,23 +292,24 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     __shared__ V stage[STAGED ? SORT_TILE : 1];        // keys (as words), then values, in digit order
     uint32_t *stage_keys = reinterpret_cast<uint32_t *>(stage);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const SeqBlock wg = segs.count ? SeqBlock{blockIdx.y, blockIdx.x} : seq_block();
     if (segs.count) {
-        n = seg_pick(segs.n, blockIdx.y);
-        nb = seg_pick(segs.nb, blockIdx.y);
-        if (blockIdx.x >= nb) return;
-        const uint32_t base = seg_pick(segs.base, blockIdx.y);
+        n = seg_pick(segs.n, wg.seq);
+        nb = seg_pick(segs.nb, wg.seq);
+        if (wg.block >= nb) return;
+        const uint32_t base = seg_pick(segs.base, wg.seq);
         if (!WORDS) { keys_in += base; keys_out += base; }
         vals_in += base; vals_out += base;
-        hist_rows += seg_pick(segs.hbase, blockIdx.y);
+        hist_rows += seg_pick(segs.hbase, wg.seq);
     } else {
-        if (!WORDS) { keys_in += (size_t)blockIdx.y * n; keys_out += (size_t)blockIdx.y * n; }
-        vals_in += (size_t)blockIdx.y * n; vals_out += (size_t)blockIdx.y * n;
-        hist_rows += (size_t)blockIdx.y * RADIX_SIZE * nb;
+        if (!WORDS) { keys_in += (size_t)wg.seq * n; keys_out += (size_t)wg.seq * n; }
+        vals_in += (size_t)wg.seq * n; vals_out += (size_t)wg.seq * n;
+        hist_rows += (size_t)wg.seq * RADIX_SIZE * nb;
     }
     const int word_shift = shift;   // WORDS: position of the digit inside the 64-bit word
     if (WORDS) shift = 0;
     const int digit_bits = __popc(mask);
-    digit_total += (size_t)blockIdx.y * RADIX_SIZE;
+    digit_total += (size_t)wg.seq * RADIX_SIZE;
     // first position of digit d in the output: exclusive scan of the 256 digit totals
     uint32_t digit_base;
     {
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
     __syncthreads();
 
-    const uint32_t tile_base = blockIdx.x * SORT_TILE;
+    const uint32_t tile_base = wg.block * SORT_TILE;
     const uint32_t tile_count = min((uint32_t)SORT_TILE, n - tile_base);
     const uint32_t wbase = tile_base + wave * (SORT_ITEMS * 64);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
         uint32_t c[SORT_WAVES], sum = 0;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) { c[w] = cnt[w][d]; sum += c[w]; }
-        const uint32_t gb = digit_base + hist_rows[d * nb + blockIdx.x];
+        const uint32_t gb = digit_base + hist_rows[d * nb + wg.block];
         uint32_t run;
         if (STAGED) {
             uint32_t all;
