@@ -13,6 +13,9 @@ timeout -k 10 240 python bench.py > $out/bench_line.json 2> $out/bench_line.err
 cp $out/prof/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 python tools/trace_timeline.py $out/prof > $out/step_timeline.txt
 python tools/trace_gaps.py $out/prof 24 >> $out/step_timeline.txt
+python tools/trace_idle.py $out/prof 15 >> $out/step_timeline.txt
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace -d "$root/$out/prof1" --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline --views 1 --steps 20 > /dev/null 2> "$root/$out/prof1.err")
+python tools/trace_one_view_step.py $out/prof1 8 > $out/one_view_step_timeline.txt
 python tools/kstats.py $out/prof 12
 bash tools/traffic_passes.sh $out/traffic
 python tools/traffic_json.py $out/traffic $out/traffic.json
@@ -27,5 +30,5 @@ timeout -k 10 200 python bench.py --no-cpu-baseline --train-iter > $out/train_it
 timeout -k 10 200 bash tools/bench_dist1.sh > $out/one_rank_rccl_line.json 2>/dev/null
 timeout -k 10 300 python bench.py --no-cpu-baseline --train-iter --gaussians 3000000 > $out/config4_train_iter_line.json 2>/dev/null
 timeout -k 10 300 python bench.py --no-cpu-baseline --forward-only --gaussians 6000000 --width 3840 --height 2160 --views 2 --steps 3 > $out/config5_forward_line.json 2>/dev/null
-rm -rf $out/prof $out/pmc/pass*/ $out/traffic/rdreq/*/*agent_info.csv $out/traffic/write/*/*agent_info.csv
+rm -rf $out/prof $out/prof1 $out/pmc/pass*/ $out/traffic/rdreq/*/*agent_info.csv $out/traffic/write/*/*agent_info.csv
 ls $out
