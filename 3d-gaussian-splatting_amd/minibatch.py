@@ -81,6 +81,16 @@ def _front_stream(dev):
     return _front_streams[key]
 
 
+_sums_streams = {}
+
+
+def _sums_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _sums_streams:
+        _sums_streams[key] = torch.cuda.Stream(device=dev)
+    return _sums_streams[key]
+
+
 def _front_follows(front, cur):
     """Orders whatever is enqueued on the side stream from now on after everything enqueued on ``cur`` so far."""
     if front is not cur:
@@ -90,7 +100,7 @@ def _front_follows(front, cur):
 
 
 def reserve_streams(device=None):
-    """Creates the two side streams of the pipelined minibatch (front part of the next views, counter read-back)
+    """Creates the three side streams of the pipelined minibatch (front part of the next views, record sums, counter read-back)
     and runs a trivial operation on each, which binds them to hardware queues of their own.
 
     Call this BEFORE ``torch.distributed.init_process_group("nccl", ...)``.  A process has few hardware queues
@@ -101,7 +111,7 @@ def reserve_streams(device=None):
     changed.  (Raising ``GPU_MAX_HW_QUEUES`` to 8 before the first HIP call has the same effect.)"""
     from . import rasterizer as R
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    for stream in (_front_stream(dev), R._copy_stream(dev)):
+    for stream in (_front_stream(dev), _sums_stream(dev), R._copy_stream(dev)):
         with torch.cuda.stream(stream):
             torch.zeros(1, device=dev).add_(1.0)
     torch.cuda.synchronize(dev)
@@ -175,6 +185,8 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     for i in range(len(begun), min(max(lookahead, 1), len(views))):
         begin(i)
     states, live, gsums = [], [], []
+    sums = _sums_stream(dev) if front is not cur and cotangent is not None else cur
+    pending = None
     for i in range(len(views)):
         st = begun[i]
         if batch_lists:
@@ -196,7 +208,30 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
         if cotangent is None:
             continue
         live.append(st)
-        gsums.append(R.backward_records(st, cotangent(i, st)))
+        if sums is cur:
+            gsums.append(R.backward_records(st, cotangent(i, st)))
+            continue
+        # The record sums of a view (bound by memory bandwidth) run on a stream of their own beside the forward of the
+        # next view (bound by instruction issue).  The records stay referenced until the current stream has waited for
+        # the sums: memory that the allocator hands out again is then only written after they have been read.
+        dimg = cotangent(i, st)
+        if pending is not None:
+            cur.wait_event(pending[1])
+            pending = None
+        pairgrad = R.backward_composite(st, dimg)
+        composited = torch.cuda.Event()
+        composited.record(cur)
+        gsum = torch.empty(st.n, 12, dtype=torch.float32, device=dev)
+        with torch.cuda.stream(sums):
+            sums.wait_event(composited)
+            R.record_sums(st, pairgrad, gsum)
+            summed = torch.cuda.Event()
+            summed.record(sums)
+        pending = (pairgrad, summed)
+        gsums.append(gsum)
+    if pending is not None:
+        cur.wait_event(pending[1])
+        pending = None
     if cotangent is None:
         _front_follows(front, cur)
         return states, None, []

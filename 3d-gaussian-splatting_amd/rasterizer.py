@@ -437,21 +437,33 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     return grads
 
 
+def backward_composite(st: RenderState, dimg) -> torch.Tensor:
+    """Compositing backward of one view on the current stream.  Returns the gradient records of its pairs, for
+    ``record_sums``."""
+    lib = _lib.load()
+    dev = st.mask_u8.device
+    dimg = dimg.to(torch.float32).contiguous()
+    pairgrad = _alloc_pairgrad(lib, st, dev)
+    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec),
+          _ptr(st.final_T), _ptr(dimg), st.num_pairs, _ptr(pairgrad), _stream(dev))
+    return pairgrad
+
+
+def record_sums(st: RenderState, pairgrad: torch.Tensor, gsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The per-Gaussian sums of a view's gradient records, on the current stream: gsum [N,12]."""
+    lib = _lib.load()
+    dev = st.mask_u8.device
+    if gsum is None:
+        gsum = torch.empty(st.n, 12, dtype=torch.float32, device=dev)
+    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, int(lib.gsr_pairgrad_parts(st.view.tile_length)), _ptr(st.mask_u8),
+          _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad), _ptr(gsum), _stream(dev))
+    return gsum
+
+
 def backward_records(st: RenderState, dimg) -> torch.Tensor:
     """First half of the backward of one view: compositing backward, then the per-Gaussian sums of
     its gradient records.  Returns gsum [N,12]; pass it with the state to ``backward_views``."""
-    lib = _lib.load()
-    dev = st.mask_u8.device
-    stream = _stream(dev)
-    f32 = dict(dtype=torch.float32, device=dev)
-    dimg = dimg.to(torch.float32).contiguous()
-    I = st.num_pairs
-    pairgrad = _alloc_pairgrad(lib, st, dev)
-    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T), _ptr(dimg), I, _ptr(pairgrad), stream)
-    gsum = torch.empty(st.n, 12, **f32)
-    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, int(lib.gsr_pairgrad_parts(st.view.tile_length)), _ptr(st.mask_u8),
-          _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad), _ptr(gsum), stream)
-    return gsum
+    return record_sums(st, backward_composite(st, dimg))
 
 
 def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grads=None, accumulate=False, g_colors=None):
