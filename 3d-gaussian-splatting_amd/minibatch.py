@@ -124,7 +124,8 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     Stage 1 and the depth order of ALL views are one set of launches (``batch_front``: the parameters are read
     once, the sort kernels take the views as a batch).  The rest of a view's front part (pair emission, tile sort,
     record stream: bound by memory bandwidth) runs on a side stream beside the compositing of the view before it
-    (forward, backward, record sums: bound by vector instruction issue).  Without ``batch_front`` the whole front
+    (forward, backward: bound by vector instruction issue); the record sums of a view run on a third stream beside the
+    forward of the next one.  Without ``batch_front`` the whole front
     part of view i+1.. runs on the side stream, ``lookahead`` views begun before the first one's counters are
     waited for, so that the host never stalls the GPU.
 

@@ -18,7 +18,7 @@ import os
 import sys
 import time
 
-# The view minibatch is pipelined over two HIP streams and the counter read-back uses a third; with RCCL's own
+# The view minibatch is pipelined over three HIP streams and the counter read-back uses a fourth; with RCCL's own
 # streams a process runs out of HIP's default of 4 hardware queues, and streams that share a queue execute one
 # after the other.  main() therefore binds the side streams to queues before the process group exists
 # (gsplat_amd.minibatch.reserve_streams); where the environment leaves the number of queues open, ask for 8
@@ -191,7 +191,7 @@ def main():
     exchange_events = None
 
     def step(overlap=True):
-        # The rank's views are software-pipelined over two streams (minibatch.render_views): stage 1,
+        # The rank's views are software-pipelined over three streams (minibatch.render_views): stage 1,
         # sorts and lists of the next views run beside the compositing of the current one; ONE pass then
         # chains all views to the raw parameters and writes the gradient bucket.
         states, _, g_screens = render_views(params, views, None if args.forward_only else cotangent,
@@ -324,7 +324,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_measured_at_pairs": traffic_pairs,
                 "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": round(dom_ms, 4),
                 "avg_launch_ms_alone": None if dom_alone_ms is None else round(dom_alone_ms, 4),
-                "note": "compositing is bound by vector instruction issue at these list lengths (SQ counters: profiles/r02m_pmc_composite_sq.txt), not by HBM; "
+                "note": "compositing is bound by vector instruction issue at these list lengths (SQ counters: profiles/r02n_pmc_composite_sq.txt), not by HBM; "
                         "traffic = HBM-side bytes of one launch of this kernel on this workload's first view from the PMC passes under profiles/ (traffic.json); avg_launch_ms is measured in "
                         "the timed region, where the next view's pair emission, tile sort and record stream run beside the kernel on a second "
                         "stream and share the CUs with it (avg_launch_ms_alone: the same launch with nothing beside it); "
