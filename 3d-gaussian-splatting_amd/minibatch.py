@@ -108,7 +108,7 @@ def reserve_streams(device=None):
     RCCL takes its share when the process group is initialised.  Side streams first used after that end up on the
     queue of the stream they are meant to run beside, and everything ``render_views`` enqueues is then executed one
     kernel after the other: measured on the headline workload, 15.1 ms per step instead of 13.5 with nothing else
-    changed.  (Raising ``GPU_MAX_HW_QUEUES`` to 8 before the first HIP call has the same effect.)"""
+    changed."""
     from . import rasterizer as R
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     for stream in (_front_stream(dev), _sums_stream(dev), R._copy_stream(dev)):
