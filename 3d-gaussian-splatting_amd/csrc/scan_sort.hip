@@ -89,17 +89,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
     if (gathered) gathered += (size_t)wg.seq * n;
     block_sums += (size_t)wg.seq * gridDim.x;
     uint32_t *overflow_flag = cnt.overflow_flag ? cnt.overflow_flag + (size_t)wg.seq * cnt.stride : nullptr;
-    const uint32_t base = wg.block * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    // (only the block's total matters here: thread t takes the elements t, t + 256, ... of the block, so that the
+    // index reads and the gathered writes of a wave are 256 consecutive bytes per instruction)
+    const uint32_t base = wg.block * SCAN_TILE + threadIdx.x;
     uint32_t s = 0;
     unsigned long long s64 = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) {
-            const uint32_t x = in[idx ? idx[base + k] : base + k];
-            if (gathered) gathered[base + k] = x;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k * SCAN_THREADS;
+        if (i < n) {
+            const uint32_t x = in[idx ? idx[i] : i];
+            if (gathered) gathered[i] = x;
             s += x;
             s64 += x;
         }
+    }
     if (overflow_flag) {
         // the block's sum in 64 bits: a sum that does not fit 32 bits raises bit 1 of the flag word
         if (threadIdx.x == 0) wide = 0ull;
@@ -164,27 +168,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
     if (idx) idx += (size_t)wg.seq * n;
     if (out_seq) out_seq += (size_t)wg.seq * (n + 1);
     block_sums += (size_t)wg.seq * gridDim.x;
-    const uint32_t base = wg.block * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS], at[SCAN_ITEMS];
-    uint32_t s = 0;
+    // Wave w takes the elements [w * 512, (w + 1) * 512) of the block's 2048, 64 consecutive ones per load: every
+    // instruction of a wave reads (and, for out_seq, writes) 256 consecutive bytes.  The prefix of an element is the
+    // sum of the rows before it in the wave, the lanes before it in its row, the waves before it in the block.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base = wg.block * SCAN_TILE + wave * (SCAN_ITEMS * 64) + lane;
+    uint32_t v[SCAN_ITEMS], at[SCAN_ITEMS], before[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        at[k] = base + k < n ? (idx ? idx[base + k] : base + k) : 0u;
-        v[k] = base + k < n ? (gathered ? gathered[base + k] : in[at[k]]) : 0u;
-        s += v[k];
+        const uint32_t i = base + k * 64;
+        at[k] = i < n ? (idx ? idx[i] : i) : 0u;
+        v[k] = i < n ? (gathered ? gathered[i] : in[at[k]]) : 0u;
     }
-    uint32_t total;
-    uint32_t run = block_sums[wg.block] + block_exclusive_scan(s, lds, total);
+    uint32_t rows = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) {
-            out[at[k]] = run;
+        const uint32_t inc = wave_inclusive_scan(v[k]);
+        before[k] = rows + inc - v[k];
+        rows += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) lds[wave] = rows;
+    __syncthreads();
+    uint32_t run = block_sums[wg.block];
+    for (int w = 0; w < wave; ++w) run += lds[w];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k * 64;
+        if (i < n) {
+            const uint32_t r = run + before[k];
+            out[at[k]] = r;
             if (out_seq) {
-                out_seq[base + k] = run;
-                if (base + k == n - 1) out_seq[n] = run + v[k];
+                out_seq[i] = r;
+                if (i == n - 1) out_seq[n] = r + v[k];
             }
         }
-        run += v[k];
     }
 }
 
