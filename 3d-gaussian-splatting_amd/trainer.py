@@ -192,10 +192,13 @@ class MinibatchTrainer(Trainer):
             live = [st for st in states if st.num_visible]
             # the reference draws again when nothing is visible (Trainer.py:52-55): here, when no view of
             # the step on any rank shows anything
-            seen = torch.tensor([float(len(live))], device=dev)
             if world > 1:
+                seen = torch.tensor([float(len(live))], device=dev)
                 dist.all_reduce(seen, group=self.group)
-            if float(seen) > 0:
+                any_seen = float(seen) > 0
+            else:
+                any_seen = bool(live)       # (no device round trip: the host stays ahead of the GPU from step to step)
+            if any_seen:
                 break
         loss = torch.stack(losses).sum() / V if losses else torch.zeros((), device=dev)
         if world > 1:
