@@ -31,7 +31,7 @@ SYMBOLS = (
     "gsr_composite_fwd", "gsr_composite_bwd", "gsr_pairgrad_parts",
     "gsr_loss_workspace_bytes", "gsr_loss_fwd_bwd",
     "gsr_adam_step", "gsr_knn_dist2",
-    "gsr_densify_stats", "gsr_densify_select_workspace_bytes", "gsr_densify_select", "gsr_densify_apply",
+    "gsr_densify_stats", "gsr_densify_stats_views", "gsr_densify_select_workspace_bytes", "gsr_densify_select", "gsr_densify_apply",
     "gsr_remove_select_workspace_bytes", "gsr_remove_select", "gsr_remove_apply_workspace_bytes", "gsr_remove_apply",
 )
 
@@ -123,6 +123,7 @@ def load():
                                   [C.c_double] * 4 + [vp])
     lib.gsr_knn_dist2.argtypes = [C.c_uint32, vp, vp, vp]
     lib.gsr_densify_stats.argtypes = [C.c_uint32, vp, vp, vp, vp, vp]
+    lib.gsr_densify_stats_views.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
     lib.gsr_densify_select.argtypes = [C.c_uint32, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_densify_apply.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32] + [vp] * 9 + [vp]
     lib.gsr_remove_select.argtypes = [C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp]

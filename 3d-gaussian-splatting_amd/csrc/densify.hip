@@ -31,6 +31,31 @@ __global__ __launch_bounds__(kThreads) void stats_kernel(uint32_t n, const uint8
     denom[i] += 1;
 }
 
+// stats_kernel for the views of one step in one launch: a thread adds its row's contributions in the order of the
+// views, which is the order of the float additions of one launch per view.
+struct StatsViews {
+    int nv;
+    const uint8_t *mask[GSR_MAX_VIEWS];
+    const float *g_screen[GSR_MAX_VIEWS];
+};
+__global__ __launch_bounds__(kThreads) void stats_views_kernel(uint32_t n, StatsViews a, float *__restrict__ coords_grads,
+                                                               int32_t *__restrict__ denom)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    float sum = 0.0f;
+    int32_t seen = 0;
+    bool any = false;
+    for (int v = 0; v < a.nv; ++v) {
+        if (!a.mask[v][i]) continue;
+        const float gx = a.g_screen[v][3 * (size_t)i], gy = a.g_screen[v][3 * (size_t)i + 1];
+        if (!any) { sum = coords_grads[i]; any = true; }
+        sum += sqrtf(gx * gx + gy * gy);
+        ++seen;
+    }
+    if (any) { coords_grads[i] = sum; denom[i] += seen; }
+}
+
 // GaussianModel.py:236-244 for the rows below the size.  A row is cloned when its mean gradient
 // reaches the threshold and its largest raw scale is at most the scale threshold, split when the
 // scale is larger: the two sets are disjoint and a cloned copy can never be split, so one pass over
@@ -205,6 +230,28 @@ extern "C" int gsr_densify_stats(uint32_t n, const uint8_t *mask, const float *g
     hipLaunchKernelGGL(stats_kernel, dim3(gsr_div_up(n, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, n, mask,
                        g_screen, coords_grads, denom);
     return gsr_check_launch("densify_stats");
+}
+
+extern "C" int gsr_densify_stats_views(uint32_t n, uint32_t num_views, const uint8_t *const *mask_host,
+                                       const float *const *g_screen_host, float *coords_grads, int32_t *denom, void *stream)
+{
+    if (n == 0 || num_views == 0) return GSR_OK;
+    if (!mask_host || !g_screen_host || !coords_grads || !denom) { gsr_set_error("gsr_densify_stats_views: null pointer"); return GSR_ERR_ARG; }
+    for (uint32_t v0 = 0; v0 < num_views; v0 += GSR_MAX_VIEWS) {
+        StatsViews a;
+        a.nv = (int)((num_views - v0 < (uint32_t)GSR_MAX_VIEWS) ? num_views - v0 : (uint32_t)GSR_MAX_VIEWS);
+        for (int k = 0; k < GSR_MAX_VIEWS; ++k) {
+            a.mask[k] = k < a.nv ? mask_host[v0 + k] : nullptr;
+            a.g_screen[k] = k < a.nv ? g_screen_host[v0 + k] : nullptr;
+            if (k < a.nv && (!a.mask[k] || !a.g_screen[k])) {
+                gsr_set_error("gsr_densify_stats_views: null pointer for view %u", v0 + k);
+                return GSR_ERR_ARG;
+            }
+        }
+        hipLaunchKernelGGL(stats_views_kernel, dim3(gsr_div_up(n, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, n, a,
+                           coords_grads, denom);
+    }
+    return gsr_check_launch("densify_stats_views");
 }
 
 extern "C" size_t gsr_densify_select_workspace_bytes(uint32_t size) { return gsr_scan_workspace_bytes(size); }

@@ -58,6 +58,33 @@ def accumulate_stats(model, g_screen: torch.Tensor, mask: torch.Tensor):
           model._coords_grads.data_ptr(), model._denom.data_ptr(), _stream(g_screen.device))
 
 
+def _stats_views(size: int, g_screens, masks, coords_grads, denom):
+    """``gsr_densify_stats_views``: the contributions of several views with one launch (per 8 views), added in the
+    order of the views - bit for bit what one ``gsr_densify_stats`` call per view leaves."""
+    import ctypes as C
+    if len(g_screens) != len(masks):
+        raise ValueError(f"{len(g_screens)} gradients for {len(masks)} masks")
+    if not g_screens:
+        return
+    dev = g_screens[0].device
+    keep = []
+    for g, mask in zip(g_screens, masks):
+        if tuple(g.shape) != (size, 3) or not g.is_cuda or g.dtype != torch.float32:
+            raise ValueError(f"g_screen has shape {tuple(g.shape)}, expected float32 [{size},3] on the GPU")
+        keep.append((g.contiguous(), _mask_u8(mask, size)))
+    nv = len(keep)
+    grads_p = (C.c_void_p * nv)(*[g.data_ptr() for g, _ in keep])
+    masks_p = (C.c_void_p * nv)(*[m.data_ptr() for _, m in keep])
+    _call("gsr_densify_stats_views", _lib.load().gsr_densify_stats_views, size, nv, masks_p, grads_p, coords_grads.data_ptr(),
+          denom.data_ptr(), _stream(dev))
+
+
+@torch.no_grad()
+def accumulate_stats_views(model, g_screens, masks):
+    """``accumulate_stats`` for the views of one step (``g_screens`` and ``masks`` in the order of the views)."""
+    _stats_views(int(model._size), g_screens, masks, model._coords_grads, model._denom)
+
+
 @torch.no_grad()
 def stats_delta(size: int, g_screens, masks):
     """What ``update_densify_stats`` would add for several views, as tensors of their own:
@@ -71,13 +98,7 @@ def stats_delta(size: int, g_screens, masks):
     dev = g_screens[0].device
     grads = torch.zeros((size, 1), dtype=torch.float32, device=dev)
     denom = torch.zeros((size, 1), dtype=torch.int32, device=dev)
-    lib = _lib.load()
-    for g, mask in zip(g_screens, masks):
-        if tuple(g.shape) != (size, 3) or not g.is_cuda or g.dtype != torch.float32:
-            raise ValueError(f"g_screen has shape {tuple(g.shape)}, expected float32 [{size},3] on the GPU")
-        m8 = _mask_u8(mask, size)
-        _call("gsr_densify_stats", lib.gsr_densify_stats, size, m8.data_ptr(), g.contiguous().data_ptr(),
-              grads.data_ptr(), denom.data_ptr(), _stream(dev))
+    _stats_views(size, g_screens, masks, grads, denom)
     return grads, denom
 
 

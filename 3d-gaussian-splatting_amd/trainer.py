@@ -218,8 +218,7 @@ class MinibatchTrainer(Trainer):
                     dd = torch.zeros((size, 1), dtype=torch.int32, device=dev)
                 reduce_densify_stats(model, dg, dd, group=self.group)
             else:
-                for st, gs in zip(live, g_screens):
-                    D.accumulate_stats(model, gs, st.mask_u8)
+                D.accumulate_stats_views(model, g_screens, [st.mask_u8 for st in live])
             if train_step > 0 and train_step % 500 == 0:
                 model.add_sh_degree()
             grew = False

@@ -172,7 +172,7 @@ def main():
     stats = {}
     model = opt = None
     if args.train_iter:
-        from gsplat_amd.densify import accumulate_stats, stats_delta
+        from gsplat_amd.densify import accumulate_stats_views, stats_delta
         from gsplat_amd.minibatch import reduce_densify_stats
         from gsplat_amd.model import GaussianModel
         from gsplat_amd.optimizer import Adam
@@ -224,8 +224,7 @@ def main():
                     dd = torch.zeros((n, 1), dtype=torch.int32, device=dev)
                 reduce_densify_stats(model, dg, dd)
             else:
-                for st, gs in zip(live, g_screens):
-                    accumulate_stats(model, gs, st.mask_u8)
+                accumulate_stats_views(model, g_screens, [st.mask_u8 for st in live])
             opt.step(grads=bucket.views)
 
     def sync():

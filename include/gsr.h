@@ -320,6 +320,13 @@ int gsr_adam_step(uint32_t num_tensors, float *const *param_host, const float *c
 int gsr_densify_stats(uint32_t n, const uint8_t *mask, const float *g_screen, float *coords_grads,
                       int32_t *denom, void *stream);
 
+/* gsr_densify_stats for the num_views views of one step with one launch per GSR_MAX_VIEWS views (Trainer.py:61 calls
+ * update_densify_stats once per rendered view; a step of several views calls it once per view).  mask_host /
+ * g_screen_host: HOST arrays of num_views device pointers.  A row's contributions are added in the order of the
+ * views, so the result equals num_views calls of gsr_densify_stats bit for bit. */
+int gsr_densify_stats_views(uint32_t n, uint32_t num_views, const uint8_t *const *mask_host,
+                            const float *const *g_screen_host, float *coords_grads, int32_t *denom, void *stream);
+
 /* Selection of GaussianModel.densify (GaussianModel.py:236-244): with g = coords_grads / denom
  * (nan -> 0) and s = the largest RAW scale of the row, row i < size is cloned when
  * |g| >= grad_threshold and s <= scale_threshold, split when |g| >= grad_threshold and

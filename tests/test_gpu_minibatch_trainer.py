@@ -131,3 +131,29 @@ def test_stats_delta_of_two_halves_is_the_statistics_of_all_views():
         D.stats_delta(size, gs[:2], masks[:1])
     with pytest.raises(ValueError):
         D.stats_delta(size + 1, gs[:1], masks[:1])
+
+
+@pytest.mark.parametrize("nviews", [1, 3, 8, 11])
+def test_statistics_of_a_step_in_one_launch_equal_one_launch_per_view(nviews):
+    """accumulate_stats_views (gsr_densify_stats_views, groups of 8 views) leaves, bit for bit, what accumulate_stats
+    called view after view leaves: the same float additions in the same order; rows beyond the size are not touched."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd import densify as D
+    from gsplat_amd.model import GaussianModel
+    start, _, _ = _setup(n=5000)
+    size = 4321
+    one = GaussianModel(*start, sh_degree=1, size=size)
+    two = GaussianModel(*start, sh_degree=1, size=size)
+    gen = torch.Generator().manual_seed(78)
+    for m in (one, two):
+        m._coords_grads.copy_(torch.rand(5000, 1, generator=torch.Generator().manual_seed(3)).to(dev()))
+        m._denom.fill_(2)
+    gs = [(torch.randn(size, 3, generator=gen) * 1e-3).to(dev()) for _ in range(nviews)]
+    masks = [(torch.rand(size, generator=gen) < 0.5).to(dev()) for _ in range(nviews)]
+    for g, m in zip(gs, masks):
+        D.accumulate_stats(one, g, m)
+    D.accumulate_stats_views(two, gs, masks)
+    assert torch.equal(one._denom, two._denom)
+    assert torch.equal(one._coords_grads.view(torch.int32), two._coords_grads.view(torch.int32))
+    with pytest.raises(ValueError):
+        D.accumulate_stats_views(two, gs, masks[:-1] if nviews > 1 else [])
