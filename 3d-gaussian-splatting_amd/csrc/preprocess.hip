@@ -935,10 +935,6 @@ extern "C" int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num
         gsr_set_error("gsr_preprocess_bwd_views: null pointer");
         return GSR_ERR_ARG;
     }
-    if (!g_sh && !g_color_host) {
-        gsr_set_error("gsr_preprocess_bwd_views: g_sh may only be left out when the colour gradients are asked for");
-        return GSR_ERR_ARG;
-    }
     ViewK first;
     if (int e = gsr_make_view(&views_host[0], &first)) return e;
     if (first.n == 0) return GSR_OK;

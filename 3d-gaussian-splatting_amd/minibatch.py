@@ -118,7 +118,8 @@ def reserve_streams(device=None):
 
 
 def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Optional[Callable], grads=None,
-                 accumulate: bool = False, overlap: bool = True, lookahead: int = 2, g_colors=None, batch_front: bool = True):
+                 accumulate: bool = False, overlap: bool = True, lookahead: int = 2, g_colors=None, batch_front: bool = True,
+                 colors_ready: Optional[Callable] = None):
     """Forward + backward of the views of one rank against the same parameters.
 
     Stage 1 and the depth order of ALL views are one set of launches (``batch_front``: the parameters are read
@@ -134,7 +135,10 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     ``state.img`` is enqueued); ``None`` renders forward only.  The five dense gradients are written to
     (``accumulate``: added to) ``grads`` by ONE pass over all views.  ``g_colors`` (a ``[len(views),N,3]``
     tensor): the sh gradient is left out and the colour gradient of every view is stored there instead,
-    for ``reduce_gradients``.  ``batch_front``: stage 1 and the depth order of all views at once
+    for ``reduce_gradients`` - the colour gradient of a view is three columns of its record sums, copied as soon as
+    the sums exist, and ``colors_ready()`` (if given) is called with all of them enqueued and ordered before the current
+    stream's next work, BEFORE the pass that chains the views to the parameters: a caller that gathers them from other
+    ranks starts its collective there, beside that pass.  ``batch_front``: stage 1 and the depth order of all views at once
     (``rasterizer.forward_begin_views``) instead of view by view; the results are bit-identical.
     Returns ``(states, grads, g_screens)`` - ``states`` holds every view (``num_visible == 0`` ones have
     no image), ``g_screens`` one tensor per view that had something visible."""
@@ -211,6 +215,8 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
         live.append(st)
         if sums is cur:
             gsums.append(R.backward_records(st, cotangent(i, st)))
+            if g_colors is not None:
+                g_colors[i].copy_(gsums[-1][:, COLOR_COLUMNS])
             continue
         # The record sums of a view (bound by memory bandwidth) run on a stream of their own beside the forward of the
         # next view (bound by instruction issue).  The records stay referenced until the current stream has waited for
@@ -226,6 +232,8 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
         with torch.cuda.stream(sums):
             sums.wait_event(composited)
             R.record_sums(st, pairgrad, gsum)
+            if g_colors is not None:
+                g_colors[i].copy_(gsum[:, COLOR_COLUMNS])
             summed = torch.cuda.Event()
             summed.record(sums)
         pending = (pairgrad, summed)
@@ -236,13 +244,13 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     if cotangent is None:
         _front_follows(front, cur)
         return states, None, []
-    cols = None
     if g_colors is not None:
-        cols = [g_colors[i] for i, st in enumerate(states) if st.num_visible]
         for i, st in enumerate(states):
             if not st.num_visible:
                 g_colors[i].zero_()
-    grads, g_screens = R.backward_views(live, gsums, *params, grads=grads, accumulate=accumulate, g_colors=cols)
+        if colors_ready is not None:
+            colors_ready()
+    grads, g_screens = R.backward_views(live, gsums, *params, grads=grads, accumulate=accumulate, skip_sh=g_colors is not None)
     _front_follows(front, cur)
     return states, grads, g_screens
 
@@ -250,6 +258,9 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
 # render_views builds the lists of all views of a step with one set of launches when their record streams together
 # are at most this large (about two thirds of the 256 MB last-level cache of an MI355X)
 BATCHED_LISTS_MAX_STREAM_BYTES = int(os.environ.get("GSR_BATCHED_LISTS_MAX_MB", "160")) << 20
+
+# dL/d(colour) of a view as it reaches the clamp: columns 6..8 of its record sums (zero rows for culled Gaussians)
+COLOR_COLUMNS = slice(6, 9)
 
 SMALL_FLOATS = sum(FIELD_SIZES[:4])     # coords, scale, rotation, opacity: what is summed over the ranks
 
@@ -266,8 +277,26 @@ def factored_moves_less(n_views: int) -> bool:
     return 3 * n_views < 2 * 48
 
 
+def gather_colors(g_colors_local: torch.Tensor, n_views: int, group=None, force_collectives: bool = False):
+    """Starts the gather of the ranks' colour gradients (``[V/world, N, 3]`` each) into ``[V, N, 3]`` and returns
+    ``(g_all, work)`` for ``reduce_gradients(..., gathered=...)``, or ``None`` where the gather is left to
+    ``reduce_gradients`` (one rank without ``force_collectives``, or a backend other than RCCL).  Meant to be called
+    from ``render_views``'s ``colors_ready``: the collective then runs beside the pass that chains the views to the
+    parameters, whose results the sum over the ranks has to wait for anyway."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    world = dist.get_world_size(group)
+    if (world == 1 and not force_collectives) or dist.get_backend(group) != "nccl":
+        return None
+    if not can_factor(n_views, world) or g_colors_local.dim() != 3 or g_colors_local.shape[0] != n_views // world:
+        raise ValueError(f"g_colors_local has shape {tuple(g_colors_local.shape)}, expected [{n_views}/{world},N,3]")
+    g_all = torch.empty((n_views,) + tuple(g_colors_local.shape[1:]), dtype=g_colors_local.dtype, device=g_colors_local.device)
+    return g_all, dist.all_gather_into_tensor(g_all, g_colors_local, group=group, async_op=True)
+
+
 def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: int, rebuild_sh: Callable, group=None,
-                     force_collectives: bool = False):
+                     force_collectives: bool = False, gathered=None):
     """Gradient exchange of one step between ranks that hold the same parameters, without moving the
     sh gradient: the 11 floats per Gaussian of coords / scale / rotation / opacity are summed with one
     all-reduce, the colour gradients of the rank's views (``g_colors_local`` ``[V/world, N, 3]``, from
@@ -276,7 +305,8 @@ def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: 
     (``rasterizer.sh_grad_views``, beside the all-reduce: the gather is issued first).  Per rank that is 11 N floats reduced and 3 N floats per view
     gathered in place of 59 N floats reduced; the sh gradient comes out identical on every rank and
     identical to a single-rank run.  ``force_collectives`` issues the two collectives for a single
-    rank too (a rehearsal of the multi-rank path).  Returns the gathered colour gradients."""
+    rank too (a rehearsal of the multi-rank path).  ``gathered``: what ``gather_colors`` returned for the same
+    ``g_colors_local`` (``None``: the gather is issued here).  Returns the gathered colour gradients."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     if not can_factor(n_views, world):
@@ -292,17 +322,20 @@ def reduce_gradients(bucket: GradBucket, g_colors_local: torch.Tensor, n_views: 
     if world == 1 and not (force_collectives and dist.is_available() and dist.is_initialized()):
         rebuild_sh(g_colors_local)
         return g_colors_local
-    g_all = torch.empty((n_views, n, 3), dtype=g_colors_local.dtype, device=g_colors_local.device)
     small = bucket.flat[:bucket.n * SMALL_FLOATS]
     if dist.get_backend(group) == "nccl":
-        # RCCL: the gather first, then the sum, both asynchronous: the sh rebuild needs only the gathered colours and
-        # runs on the compute stream while the all-reduce is still on the wire (the two are independent of each other)
-        gathered = dist.all_gather_into_tensor(g_all, g_colors_local, group=group, async_op=True)
+        # RCCL: the gather first (or earlier still: gather_colors), then the sum, both asynchronous: the sh rebuild needs
+        # only the gathered colours and runs on the compute stream while the all-reduce is still on the wire (the two are
+        # independent of each other)
+        if gathered is None:
+            gathered = gather_colors(g_colors_local, n_views, group, force_collectives=True)
+        g_all, gather_work = gathered
         summed = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        gathered.wait()
+        gather_work.wait()
         rebuild_sh(g_all)
         summed.wait()
     else:
+        g_all = torch.empty((n_views, n, 3), dtype=g_colors_local.dtype, device=g_colors_local.device)
         # other backends (gloo in the tests, which stages device tensors through the host on streams of its own):
         # one collective after the other - two of them in flight beside a kernel stalled a two-rank run on one GPU
         dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group)

@@ -466,14 +466,17 @@ def backward_records(st: RenderState, dimg) -> torch.Tensor:
     return record_sums(st, backward_composite(st, dimg))
 
 
-def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grads=None, accumulate=False, g_colors=None):
+def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grads=None, accumulate=False, g_colors=None,
+                   skip_sh: bool = False):
     """Second half for a whole view minibatch: chains the per-Gaussian sums of all views to the raw
     parameters and writes (or, with ``accumulate``, adds to) the five dense gradients ONCE.
     ``states``/``gsums``: the views that had something visible.  Returns (grads, [g_screen per view]).
 
     ``g_colors`` (one ``[N,3]`` tensor per state): the sh gradient is NOT written; instead every view's
     colour gradient is stored there, for ranks that rebuild the sh gradient of the whole minibatch
-    with ``sh_grad_views`` after gathering them (``minibatch.reduce_gradients``)."""
+    with ``sh_grad_views`` after gathering them (``minibatch.reduce_gradients``).  ``skip_sh``: the sh gradient is not
+    written and nothing takes its place (the caller has the colour gradients already: they are columns 6..8 of the
+    record sums)."""
     import ctypes as C
     lib = _lib.load()
     dev = coords.device
@@ -485,7 +488,7 @@ def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grad
     nv = len(states)
     if nv == 0:
         if not accumulate:
-            for g in (grads[:4] if g_colors is not None else grads):
+            for g in (grads[:4] if g_colors is not None or skip_sh else grads):
                 g.zero_()
         return grads, []
     g_screens = [torch.empty(n, 3, **f32) for _ in range(nv)]
@@ -506,7 +509,7 @@ def backward_views(states, gsums, coords, scale_raw, rot_raw, opac_raw, sh, grad
         opac_raw = opac_raw.unsqueeze(1)
     _call("gsr_preprocess_bwd_views", lib.gsr_preprocess_bwd_views, views, nv, _ptr(coords.contiguous()),
           _ptr(scale_raw.contiguous()), _ptr(rot_raw.contiguous()), _ptr(opac_raw.contiguous()), _ptr(sh.contiguous()),
-          masks, sums, *[_ptr(g) for g in grads[:4]], None if g_colors is not None else _ptr(grads[4]), screens, colors,
+          masks, sums, *[_ptr(g) for g in grads[:4]], None if g_colors is not None or skip_sh else _ptr(grads[4]), screens, colors,
           1 if accumulate else 0, _stream(dev))
     return grads, g_screens
 

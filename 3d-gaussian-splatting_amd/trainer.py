@@ -166,7 +166,8 @@ class MinibatchTrainer(Trainer):
         import torch.distributed as dist
         from . import densify as D
         from .loss import loss_and_grad
-        from .minibatch import can_factor, factored_moves_less, reduce_densify_stats, reduce_gradients, render_views, shard_views
+        from .minibatch import (can_factor, factored_moves_less, gather_colors, reduce_densify_stats, reduce_gradients, render_views,
+                                shard_views)
         from .rasterizer import ViewSpec, sh_grad_views
         model, V = self.model, self.views_per_step
         world, rank = self._ranks()
@@ -188,7 +189,11 @@ class MinibatchTrainer(Trainer):
                 losses.append(out[0])
                 return dpred
 
-            states, _, g_screens = render_views(params, [specs[v] for v in mine], cotangent, grads=grads, g_colors=g_colors)
+            # (the gather of the colour gradients starts as soon as they exist, beside the pass that chains the views
+            # to the parameters)
+            early = []
+            states, _, g_screens = render_views(params, [specs[v] for v in mine], cotangent, grads=grads, g_colors=g_colors,
+                                                colors_ready=lambda: early.append(gather_colors(g_colors, V, group=self.group)))
             live = [st for st in states if st.num_visible]
             # the reference draws again when nothing is visible (Trainer.py:52-55): here, when no view of
             # the step on any rank shows anything
@@ -200,11 +205,13 @@ class MinibatchTrainer(Trainer):
                 any_seen = bool(live)       # (no device round trip: the host stays ahead of the GPU from step to step)
             if any_seen:
                 break
+            if early and early[0] is not None:
+                early[0][1].wait()          # (every rank draws again: the gather of this attempt is not used)
         loss = torch.stack(losses).sum() / V if losses else torch.zeros((), device=dev)
         if world > 1:
             if factored:
                 reduce_gradients(bucket, g_colors, V, lambda g_all: sh_grad_views(specs, params[0], params[4], list(g_all), grads[4]),
-                                 group=self.group)
+                                 group=self.group, gathered=early[0] if early else None)
             else:
                 bucket.all_reduce(self.group)
             dist.all_reduce(loss, group=self.group)

@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 import gsplat_amd  # noqa: E402,F401
 from gsplat_amd.camera import Camera  # noqa: E402
-from gsplat_amd.minibatch import GradBucket, reduce_gradients, render_views, reserve_streams, shard_views  # noqa: E402
+from gsplat_amd.minibatch import GradBucket, gather_colors, reduce_gradients, render_views, reserve_streams, shard_views  # noqa: E402
 from gsplat_amd.loss import loss_and_grad  # noqa: E402
 from gsplat_amd.rasterizer import StageTimer, ViewSpec, sh_grad_views  # noqa: E402
 from gsplat_amd.scenes import synthetic_scene  # noqa: E402
@@ -193,9 +193,12 @@ def main():
         # The rank's views are software-pipelined over three streams (minibatch.render_views): stage 1,
         # sorts and lists of the next views run beside the compositing of the current one; ONE pass then
         # chains all views to the raw parameters and writes the gradient bucket.
+        # (with several ranks the gather of the colour gradients starts as soon as they exist, beside that pass)
+        early = []
         states, _, g_screens = render_views(params, views, None if args.forward_only else cotangent,
                                             grads=tuple(grads), overlap=overlap and not args.no_overlap,
-                                            g_colors=g_colors)
+                                            g_colors=g_colors,
+                                            colors_ready=lambda: early.append(gather_colors(g_colors, args.views, force_collectives=True)))
         if states and "m" not in stats:
             stats.update(m=states[0].num_visible, pairs=states[0].num_pairs)
             if states[0].num_visible and args.tile <= 16 and not args.forward_only:
@@ -208,7 +211,7 @@ def main():
                 ev[0].record()
             reduce_gradients(bucket, g_colors, args.views,
                              lambda g_all: sh_grad_views(all_views, params[0], params[4], list(g_all), bucket.sh),
-                             force_collectives=True)
+                             force_collectives=True, gathered=early[0] if early else None)
             if ev:
                 ev[1].record()
                 exchange_events.append(ev)

@@ -155,7 +155,9 @@ int gsr_preprocess_bwd_views(const gsr_view *views_host, uint32_t num_views, con
  * clamp, GaussianRenderer.py:74).  Ranks that hold the same parameters therefore need not exchange
  * the 48 sh gradient floats per Gaussian: gsr_preprocess_bwd_views with g_color_host != NULL also
  * writes g_color_host[v][N,3], the colour gradient of view v as it reaches the clamp (zero rows where
- * the Gaussian is culled), and with g_sh == NULL leaves the sh gradient out; after the ranks have
+ * the Gaussian is culled), and with g_sh == NULL leaves the sh gradient out (the colour gradient of view v is also
+ * columns 6..8 of gsum_host[v], so a caller that wants it before this pass has run copies it from there and passes
+ * g_sh == NULL and g_color_host == NULL); after the ranks have
  * gathered the colour gradients of ALL views of the minibatch, gsr_sh_grad_views rebuilds
  * g_sh[N,3,16] (written, or with accumulate != 0 added to) with the arithmetic and the view order
  * gsr_preprocess_bwd_views itself uses, so the result does not depend on the number of ranks.
