@@ -306,7 +306,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t lstart[RADIX_SIZE];            // first local position of a digit inside the tile
     __shared__ uint32_t gbase[RADIX_SIZE];             // first global position of the tile's run of a digit
     __shared__ uint32_t scan_lds[SORT_THREADS / 64 + 1];
-    __shared__ V stage[STAGED ? SORT_TILE : 1];        // keys (as words), then values, in digit order
+    // (32-bit keys with 32-bit values are staged together, as one 64-bit word per item: one pass through LDS)
+    constexpr bool PAIRED = STAGED && !WORDS && sizeof(V) == 4;
+    __shared__ V stage[STAGED && !PAIRED ? SORT_TILE : 1];        // keys (as words), then values, in digit order
+    __shared__ unsigned long long paired[PAIRED ? SORT_TILE : 1];
     uint32_t *stage_keys = reinterpret_cast<uint32_t *>(stage);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const SeqBlock wg = segs.count ? SeqBlock{blockIdx.y, blockIdx.x} : seq_block();
@@ -421,6 +424,28 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
                 const V word = stage[l];
                 const uint32_t d = word_key(word, word_shift) & mask;
                 vals_out[gbase[d] + (l - lstart[d])] = word;
+            }
+        }
+        return;
+    }
+    if (PAIRED) {
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t i = wbase + it * 64 + lane;
+            const uint32_t d = (key[it] >> shift) & mask;
+            if (i < n) paired[cnt[wave][d] + rank[it]] = (unsigned long long)key[it] | ((unsigned long long)(uint32_t)vals_in[i] << 32);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; ++it) {
+            const uint32_t l = it * SORT_THREADS + threadIdx.x;
+            if (l < tile_count) {
+                const unsigned long long kv = paired[l];
+                const uint32_t k = (uint32_t)kv;
+                const uint32_t d = (k >> shift) & mask;
+                const uint32_t at = gbase[d] + (l - lstart[d]);
+                keys_out[at] = k;
+                vals_out[at] = (V)(uint32_t)(kv >> 32);
             }
         }
         return;
