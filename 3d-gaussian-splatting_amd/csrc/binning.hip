@@ -12,13 +12,6 @@
 
 namespace {
 
-// (blockIdx.y: one of several sequences of n that lie one after the other)
-__global__ void iota_kernel(uint32_t *__restrict__ out, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[(size_t)blockIdx.y * n + i] = i;
-}
-
 // The lists of several views of the same Gaussians built by one set of launches (blockIdx.y = view): view y has
 // n[y] pairs from element base[y] (a multiple of 4096) of the per-pair arrays; the per-Gaussian inputs of view y
 // start y * N elements (rows) into their arrays, its tile offsets y * (T + 1), its tile order y * T.  count == 0: one view.
@@ -407,11 +400,10 @@ extern "C" int gsr_bin_offsets(uint32_t *depth_key, const uint32_t *ntiles, uint
     const size_t sort_bytes = gsr_sort_workspace_bytes(n);
     void *scan_ws = (char *)sort_ws + sort_bytes;
     const size_t scan_bytes = gsr_scan_workspace_bytes(n);
-    const dim3 grid(gsr_div_up(n, 256)), block(256);
-    // 32 key bits = an even number of passes: the sorted indices come back to the buffer they start in
-    hipLaunchKernelGGL(iota_kernel, grid, block, 0, st, order, n);
+    // an argsort: the first pass takes a key's position as its value.  32 key bits = an even number of passes: the
+    // sorted indices end in `order`
     bool in_first;
-    if (int e = gsr_sort_pingpong32(depth_key, order, keys_b, ids_b, n, 0, 32, sort_ws, sort_bytes, stream, &in_first))
+    if (int e = gsr_sort_pingpong32(depth_key, order, keys_b, ids_b, n, 0, 32, sort_ws, sort_bytes, stream, &in_first, true))
         return e;
     if (!in_first) { gsr_set_error("gsr_bin_offsets: unexpected number of sort passes"); return GSR_ERR_LAUNCH; }
     // slot_base[order[s]] = sum over s' < s of ntiles[order[s']]
@@ -456,10 +448,9 @@ extern "C" int gsr_bin_offsets_views(uint32_t *depth_key, const uint32_t *ntiles
     const size_t sort_bytes = (size_t)num_views * gsr_sort_workspace_bytes(n);
     void *scan_ws = (char *)sort_ws + sort_bytes;
     const size_t scan_bytes = (size_t)num_views * gsr_scan_workspace_bytes(n);
-    hipLaunchKernelGGL(iota_kernel, dim3(gsr_div_up(n, 256), num_views), dim3(256), 0, st, order, n);
     bool in_first;
     if (int e = gsr_sort_pingpong32_batch(depth_key, order, keys_b, ids_b, n, num_views, 0, 32, sort_ws, sort_bytes, stream,
-                                          &in_first))
+                                          &in_first, true))
         return e;
     if (!in_first) { gsr_set_error("gsr_bin_offsets_views: unexpected number of sort passes"); return GSR_ERR_LAUNCH; }
     if (int e = gsr_exclusive_scan_along_batch(ntiles, order, slot_base, n, num_views, &counters->num_pairs, &counters->error,

@@ -23,8 +23,10 @@ int gsr_check_launch(const char *what);
 
 // scan_sort.hip, used by binning.hip: radix sort that ping-pongs between two buffer pairs without a
 // final copy (*result_in_first: sorted data is in the *_a buffers), and a scan along a permutation.
+// positions_as_values: the values are the positions 0 .. n-1 of each sequence (an argsort); vals_a need not hold them
 int gsr_sort_pingpong32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, int begin_bit,
-                        int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
+                        int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first,
+                        bool positions_as_values = false);
 int gsr_sort_pingpong64(uint32_t *keys_a, uint64_t *vals_a, uint32_t *keys_b, uint64_t *vals_b, uint32_t n, int begin_bit,
                         int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first);
 int gsr_sort_words64(uint64_t *words_a, uint64_t *words_b, uint32_t n, int begin_bit, int end_bit, void *workspace,
@@ -36,7 +38,7 @@ int gsr_sort_words64_segs(uint64_t *words_a, uint64_t *words_b, const uint32_t *
                           bool *result_in_first);   // sequences of different lengths, each from a multiple of 4096
 int gsr_sort_pingpong32_batch(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, uint32_t nseq,
                               int begin_bit, int end_bit, void *workspace, size_t workspace_bytes, void *stream,
-                              bool *result_in_first);   // nseq sequences of n pairs, one after the other
+                              bool *result_in_first, bool positions_as_values = false);   // nseq sequences of n pairs, one after the other
 int gsr_exclusive_scan_along_batch(const uint32_t *in, const uint32_t *idx, uint32_t *out, uint32_t n, uint32_t nseq,
                                    uint32_t *total, uint32_t *overflow_flag, uint32_t counter_stride, void *workspace,
                                    size_t workspace_bytes, void *stream, uint32_t *out_seq,

@@ -296,6 +296,7 @@ template <typename V>
 __device__ inline uint32_t word_key(V word, int shift) { return (uint32_t)((unsigned long long)word >> shift); }
 
 // WORDS (V = uint64_t, STAGED): there is no key array - the digit is taken from bits shift.. of the value itself.
+// vals_in == null (not with WORDS): the value of an item is its position in its sequence (the first pass of an argsort).
 template <typename V, bool STAGED, bool WORDS = false>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
@@ -319,11 +320,13 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
         if (wg.block >= nb) return;
         const uint32_t base = seg_pick(segs.base, wg.seq);
         if (!WORDS) { keys_in += base; keys_out += base; }
-        vals_in += base; vals_out += base;
+        if (vals_in) vals_in += base;
+        vals_out += base;
         hist_rows += seg_pick(segs.hbase, wg.seq);
     } else {
         if (!WORDS) { keys_in += (size_t)wg.seq * n; keys_out += (size_t)wg.seq * n; }
-        vals_in += (size_t)wg.seq * n; vals_out += (size_t)wg.seq * n;
+        if (vals_in) vals_in += (size_t)wg.seq * n;
+        vals_out += (size_t)wg.seq * n;
         hist_rows += (size_t)wg.seq * RADIX_SIZE * nb;
     }
     const int word_shift = shift;   // WORDS: position of the digit inside the 64-bit word
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
                 const uint32_t d = (key[it] >> shift) & mask;
                 const uint32_t pos = cnt[wave][d] + rank[it];
                 keys_out[pos] = key[it];
-                vals_out[pos] = vals_in[i];
+                vals_out[pos] = vals_in ? vals_in[i] : (V)i;
             }
         }
         return;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
         for (int it = 0; it < SORT_ITEMS; ++it) {
             const uint32_t i = wbase + it * 64 + lane;
             const uint32_t d = (key[it] >> shift) & mask;
-            if (i < n) paired[cnt[wave][d] + rank[it]] = (unsigned long long)key[it] | ((unsigned long long)(uint32_t)vals_in[i] << 32);
+            if (i < n) paired[cnt[wave][d] + rank[it]] = (unsigned long long)key[it] | ((unsigned long long)(vals_in ? (uint32_t)vals_in[i] : i) << 32);
         }
         __syncthreads();
 #pragma unroll
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const uint32_t i = wbase + it * 64 + lane;
-        if (i < n) stage[lpos[it]] = vals_in[i];
+        if (i < n) stage[lpos[it]] = vals_in ? vals_in[i] : (V)i;
     }
     __syncthreads();
 #pragma unroll
@@ -607,7 +610,8 @@ extern "C" size_t gsr_sort_workspace_bytes(uint32_t n)
 // nseq times gsr_sort_workspace_bytes(n))
 template <typename V>
 static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_b, uint32_t n, int begin_bit, int end_bit,
-                         void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first, uint32_t nseq = 1)
+                         void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first, uint32_t nseq = 1,
+                         bool positions_as_values = false)
 {
     hipStream_t st = (hipStream_t)stream;
     *result_in_first = true;
@@ -636,11 +640,13 @@ static int sort_pingpong(uint32_t *keys_a, V *vals_a, uint32_t *keys_b, V *vals_
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel<uint32_t>, dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, n, bit, mask, nb, hist, no_segs);
         hipLaunchKernelGGL(radix_rows_kernel, dim3(RADIX_SIZE, nseq), dim3(256), 0, st, hist, nb, digit_total, no_segs);
+        // (positions_as_values: the values of the first pass are the positions 0 .. n-1, which nobody has to write first)
+        const V *values = positions_as_values && bit == begin_bit ? nullptr : vi;
         if (sizeof(V) > 4 || staged32)
-            hipLaunchKernelGGL((radix_scatter_kernel<V, true>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, vi, ko,
+            hipLaunchKernelGGL((radix_scatter_kernel<V, true>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, values, ko,
                                vo, n, bit, mask, nb, hist, digit_total, no_segs);
         else
-            hipLaunchKernelGGL((radix_scatter_kernel<V, false>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, vi, ko,
+            hipLaunchKernelGGL((radix_scatter_kernel<V, false>), dim3(nb, nseq), dim3(SORT_THREADS), 0, st, ki, values, ko,
                                vo, n, bit, mask, nb, hist, digit_total, no_segs);
         uint32_t *t = ki; ki = ko; ko = t;
         V *tv = vi; vi = vo; vo = tv;
@@ -744,17 +750,18 @@ int gsr_sort_words64_segs(uint64_t *words_a, uint64_t *words_b, const uint32_t *
 
 // library-internal entry points (binning.hip): sort without the final copy
 int gsr_sort_pingpong32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, int begin_bit,
-                        int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first)
+                        int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first,
+                        bool positions_as_values)
 {
     return sort_pingpong<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, workspace, workspace_bytes,
-                                   stream, result_in_first);
+                                   stream, result_in_first, 1, positions_as_values);
 }
 int gsr_sort_pingpong32_batch(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, uint32_t nseq,
                               int begin_bit, int end_bit, void *workspace, size_t workspace_bytes, void *stream,
-                              bool *result_in_first)
+                              bool *result_in_first, bool positions_as_values)
 {
     return sort_pingpong<uint32_t>(keys_a, vals_a, keys_b, vals_b, n, begin_bit, end_bit, workspace, workspace_bytes,
-                                   stream, result_in_first, nseq);
+                                   stream, result_in_first, nseq, positions_as_values);
 }
 int gsr_sort_pingpong64(uint32_t *keys_a, uint64_t *vals_a, uint32_t *keys_b, uint64_t *vals_b, uint32_t n, int begin_bit,
                         int end_bit, void *workspace, size_t workspace_bytes, void *stream, bool *result_in_first)
