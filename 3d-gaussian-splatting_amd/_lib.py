@@ -25,7 +25,7 @@ SYMBOLS = (
     "gsr_pair_reduce", "gsr_preprocess_bwd_views", "gsr_sh_grad_views",
     "gsr_sort_workspace_bytes", "gsr_sort_pairs", "gsr_sort_pairs64", "gsr_scan_workspace_bytes", "gsr_exclusive_scan",
     "gsr_exclusive_scan_static",
-    "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_offsets_views_workspace_bytes", "gsr_bin_offsets_views",
+    "gsr_bin_offsets_workspace_bytes", "gsr_bin_offsets", "gsr_bin_offsets_views_workspace_bytes", "gsr_bin_offsets_views", "gsr_slot_bases",
     "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order", "gsr_bin_lists_views_supported",
     "gsr_bin_lists_views_layout", "gsr_bin_lists_views_workspace_bytes", "gsr_bin_lists_views",
     "gsr_composite_fwd", "gsr_composite_bwd", "gsr_pairgrad_parts",
@@ -105,6 +105,7 @@ def load():
     lib.gsr_bin_offsets_views_workspace_bytes.restype = C.c_size_t
     lib.gsr_bin_offsets_views_workspace_bytes.argtypes = [C.c_uint32, C.c_uint32]
     lib.gsr_bin_offsets_views.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_slot_bases.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     lib.gsr_bin_lists.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_tile_order.argtypes = [C.POINTER(GsrView), vp, vp, vp]
     u32p = C.POINTER(C.c_uint32)

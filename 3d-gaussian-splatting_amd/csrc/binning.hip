@@ -439,7 +439,7 @@ extern "C" int gsr_bin_offsets_views(uint32_t *depth_key, const uint32_t *ntiles
         }
         return GSR_OK;
     }
-    if (!depth_key || !ntiles || !order || !slot_base) { gsr_set_error("gsr_bin_offsets_views: null pointer"); return GSR_ERR_ARG; }
+    if (!depth_key || !ntiles || !order || (!slot_base && !slot_seq)) { gsr_set_error("gsr_bin_offsets_views: null pointer"); return GSR_ERR_ARG; }
     const size_t arr = align256((size_t)n * num_views * sizeof(uint32_t));
     char *ws = (char *)workspace;
     uint32_t *ids_b = (uint32_t *)ws;             // second value buffer of the sort
@@ -458,6 +458,28 @@ extern "C" int gsr_bin_offsets_views(uint32_t *depth_key, const uint32_t *ntiles
                                                slot_seq, keys_b))
         return e;
     return gsr_check_launch("bin_offsets_views");
+}
+
+namespace {
+// slot_base[order[s]] = slot_seq[s] for the views of a step (blockIdx.y = view; n + 1 entries of slot_seq per view)
+__global__ __launch_bounds__(256) void slot_bases_kernel(const uint32_t *__restrict__ order, const uint32_t *__restrict__ slot_seq,
+                                                         uint32_t n, uint32_t *__restrict__ slot_base)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t at = (size_t)blockIdx.y * n;
+    slot_base[at + order[at + s]] = slot_seq[at + blockIdx.y + s];
+}
+}  // namespace
+
+extern "C" int gsr_slot_bases(const uint32_t *order, const uint32_t *slot_seq, uint32_t n, uint32_t num_views,
+                              uint32_t *slot_base, void *stream)
+{
+    if (n == 0 || num_views == 0) return GSR_OK;
+    if (!order || !slot_seq || !slot_base) { gsr_set_error("gsr_slot_bases: null pointer"); return GSR_ERR_ARG; }
+    hipLaunchKernelGGL(slot_bases_kernel, dim3(gsr_div_up(n, 256), num_views), dim3(256), 0, (hipStream_t)stream, order,
+                       slot_seq, n, slot_base);
+    return gsr_check_launch("slot_bases");
 }
 
 extern "C" size_t gsr_bin_lists_workspace_bytes(uint32_t num_pairs)

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const uint32_t i = base + k * 64;
-        at[k] = i < n ? (idx ? idx[i] : i) : 0u;
+        // (out == null - only with gathered and out_seq: the results are wanted in sequence order only, the permutation
+        // is not read)
+        at[k] = i < n && (out || !gathered) ? (idx ? idx[i] : i) : 0u;
         v[k] = i < n ? (gathered ? gathered[i] : in[at[k]]) : 0u;
     }
     uint32_t rows = 0;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
         const uint32_t i = base + k * 64;
         if (i < n) {
             const uint32_t r = run + before[k];
-            out[at[k]] = r;
+            if (out) out[at[k]] = r;
             if (out_seq) {
                 out_seq[i] = r;
                 if (i == n - 1) out_seq[n] = r + v[k];
@@ -521,7 +523,7 @@ int gsr_exclusive_scan_along_batch(const uint32_t *in, const uint32_t *idx, uint
         }
         return GSR_OK;
     }
-    if (!in || !out) { gsr_set_error("gsr_exclusive_scan: null pointer"); return GSR_ERR_ARG; }
+    if (!in || (!out && !(idx && gathered && out_seq))) { gsr_set_error("gsr_exclusive_scan: null pointer"); return GSR_ERR_ARG; }
     uint32_t *sums = (uint32_t *)workspace;
     const uint32_t nb = gsr_div_up(n, SCAN_TILE);
     const SegCounters cnt = {total, overflow_flag, counter_stride};

@@ -168,8 +168,18 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
         # stage 1 and the depth orders of ALL views with one set of launches (the parameters are read once, the
         # small sort kernels fill the chip, one counter read-back)
         from . import _lib
+        # The Gaussian-indexed slot bases (4-byte writes at random) are only read by the record sums of the backward:
+        # with streams to spare they are written on the sums stream, beside the lists of view 0, instead of in front of
+        # them; a forward-only call never writes them.
+        sums_apart = front is not cur
         with torch.cuda.stream(front):
-            begun.extend(R.forward_begin_views(*params, views))
+            begun.extend(R.forward_begin_views(*params, views, defer_slot_base=sums_apart))
+            if sums_apart and cotangent is not None:
+                ordered = torch.cuda.Event()
+                ordered.record(front)
+                with torch.cuda.stream(_sums_stream(dev)):
+                    _sums_stream(dev).wait_event(ordered)
+                    R.forward_slot_bases(begun)
             # The lists of all views with one set of launches as well - when the record streams of all views together
             # stay inside the GPU's last-level cache.  Larger ones are better built view by view, right before the
             # view is composited: the forward then reads most of its stream from that cache (measured: one set of

@@ -106,7 +106,7 @@ class RenderState:
     """Everything one forward leaves behind for inspection and for the backward."""
     __slots__ = ("view", "cview", "n", "num_visible", "num_pairs", "mask_u8", "pos2d", "cov2d", "radius_full",
                  "bbox", "ntiles", "rec", "order", "slot_base", "slot_seq", "tile_offsets", "tile_order", "pair_slot", "sorted_gauss",
-                 "stream_rec", "final_T", "img", "pairgrad", "_counters", "_host", "_ready")
+                 "stream_rec", "final_T", "img", "pairgrad", "_counters", "_host", "_ready", "_slot_rest", "_slot_owner")
 
     def __init__(self):
         for s in self.__slots__:
@@ -186,18 +186,23 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
     return st
 
 
-def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, projection: bool = False) -> list:
+def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, projection: bool = False,
+                        defer_slot_base: bool = False) -> list:
     """``forward_begin`` for several views of the same Gaussians (at most ``_lib.MAX_VIEWS`` per call; more are
     taken in groups): ONE pass over the parameters for stage 1 of all of them, ONE set of launches for their depth
     orders and ONE read-back of all counters.  Returns one ``RenderState`` per view, the same - bit for bit - as
     ``forward_begin`` leaves (their arrays are slices of arrays that hold all views), except that ``pos2d`` and
-    ``cov2d`` - which nothing after stage 1 reads - are only written, and kept, with ``projection=True``."""
+    ``cov2d`` - which nothing after stage 1 reads - are only written, and kept, with ``projection=True``.
+    ``defer_slot_base``: the Gaussian-indexed ``slot_base``, which only the backward's record sums read, is not written
+    here but by ``forward_slot_bases(states)`` - called by a caller with several streams beside the first view's lists,
+    or by the first ``record_sums`` that needs it."""
     lib = _lib.load()
     views = list(views)
     if len(views) > _lib.MAX_VIEWS:
         out = []
         for k in range(0, len(views), _lib.MAX_VIEWS):
-            out += forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views[k:k + _lib.MAX_VIEWS], projection)
+            out += forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views[k:k + _lib.MAX_VIEWS], projection,
+                                       defer_slot_base)
         return out
     if len(views) == 1:
         return [forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, None, views[0])]
@@ -243,8 +248,8 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, project
     slot_seq = torch.empty(nv, n + 1, **i32)
     ws_bytes = int(lib.gsr_bin_offsets_views_workspace_bytes(n, nv))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _call("gsr_bin_offsets_views", lib.gsr_bin_offsets_views, _ptr(depth_key), _ptr(ntiles), n, nv, _ptr(order), _ptr(slot_base),
-          _ptr(slot_seq), _ptr(counters), _ptr(ws), ws_bytes, stream)
+    _call("gsr_bin_offsets_views", lib.gsr_bin_offsets_views, _ptr(depth_key), _ptr(ntiles), n, nv, _ptr(order),
+          None if defer_slot_base else _ptr(slot_base), _ptr(slot_seq), _ptr(counters), _ptr(ws), ws_bytes, stream)
     states = []
     for k in range(nv):
         st = RenderState()
@@ -255,7 +260,22 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, project
         st.order, st.slot_base, st.slot_seq = order[k], slot_base[k], slot_seq[k]
         st._counters, st._host, st._ready = counters, host[k], ready
         states.append(st)
+    if defer_slot_base:
+        states[0]._slot_rest = (order, slot_seq, slot_base, n, nv)
+        for st in states:
+            st._slot_owner = states[0]
     return states
+
+
+def forward_slot_bases(states):
+    """Enqueues, on the current stream, the ``slot_base`` arrays that ``forward_begin_views(..., defer_slot_base=True)``
+    left out (once per group of views; later calls do nothing)."""
+    for st in states:
+        owner, st._slot_owner = st._slot_owner, None
+        if owner is not None and owner._slot_rest is not None:
+            (order, slot_seq, slot_base, n, nv), owner._slot_rest = owner._slot_rest, None
+            _call("gsr_slot_bases", _lib.load().gsr_slot_bases, _ptr(order), _ptr(slot_seq), n, nv, _ptr(slot_base),
+                  _stream(order.device))
 
 
 def forward_lists(st: RenderState) -> RenderState:
@@ -416,6 +436,8 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     f32 = dict(dtype=torch.float32, device=dev)
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
+    if st._slot_owner is not None:
+        forward_slot_bases([st])
     pairgrad = _alloc_pairgrad(lib, st, dev)
     _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T),
                                      _ptr(dimg), I, _ptr(pairgrad), stream)
@@ -452,6 +474,8 @@ def backward_composite(st: RenderState, dimg) -> torch.Tensor:
 def record_sums(st: RenderState, pairgrad: torch.Tensor, gsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The per-Gaussian sums of a view's gradient records, on the current stream: gsum [N,12]."""
     lib = _lib.load()
+    if st._slot_owner is not None:
+        forward_slot_bases([st])
     dev = st.mask_u8.device
     if gsum is None:
         gsum = torch.empty(st.n, 12, dtype=torch.float32, device=dev)
