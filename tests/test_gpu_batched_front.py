@@ -198,3 +198,29 @@ def test_pipelined_steps_back_to_back_equal_the_one_stream_step():
     for step, tensors in enumerate(kept):
         for a, b in zip(tensors, ref):
             _same(a, b, f"step {step}")
+
+
+@pytest.mark.parametrize("n,w,h,deg,nviews", [(3000, 200, 120, 3, 3), (70_001, 640, 360, 2, 8), (5, 64, 48, 0, 2), (40_000, 320, 200, 1, 11)])
+def test_deferred_slot_bases_equal_the_ones_of_the_scan(n, w, h, deg, nviews):
+    """forward_begin_views(defer_slot_base=True) + forward_slot_bases (gsr_slot_bases) leaves the slot bases that the
+    scan itself writes otherwise, and everything else unchanged; record_sums runs the deferred call if nobody has."""
+    from gsplat_amd import rasterizer as R
+    dev, params, views = _scene(n, w, h, deg, nviews)
+    plain = R.forward_begin_views(*params, views)
+    later = R.forward_begin_views(*params, views, defer_slot_base=True)
+    assert later[0]._slot_rest is not None and all(st._slot_owner is not None for st in later)
+    R.forward_slot_bases(later)
+    R.forward_slot_bases(later)          # (a second call does nothing)
+    torch.cuda.synchronize()
+    for k in range(nviews):
+        for f in ("order", "slot_base", "slot_seq", "ntiles"):
+            _same(getattr(later[k], f), getattr(plain[k], f), f"view {k}: {f}")
+    lazy = R.forward_begin_views(*params, views, defer_slot_base=True)
+    st = lazy[-1]
+    R.forward_finish(st)
+    if st.num_visible:
+        cot = torch.rand(w, h, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+        ref = plain[-1]
+        R.forward_finish(ref)
+        _same(R.backward_records(st, cot), R.backward_records(ref, cot), "record sums behind the lazily run call")
+    assert st._slot_owner is None or not st.num_visible
