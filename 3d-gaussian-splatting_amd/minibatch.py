@@ -164,6 +164,7 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
 
     lists_ready = None
     batch_lists = False
+    slots_written = None
     if batch_front and len(views) > 1:
         # stage 1 and the depth orders of ALL views with one set of launches (the parameters are read once, the
         # small sort kernels fill the chip, one counter read-back)
@@ -179,7 +180,9 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
                 ordered.record(front)
                 with torch.cuda.stream(_sums_stream(dev)):
                     _sums_stream(dev).wait_event(ordered)
-                    R.forward_slot_bases(begun)
+                    if R.forward_slot_bases(begun):
+                        slots_written = torch.cuda.Event()
+                        slots_written.record(_sums_stream(dev))
             # The lists of all views with one set of launches as well - when the record streams of all views together
             # stay inside the GPU's last-level cache.  Larger ones are better built view by view, right before the
             # view is composited: the forward then reads most of its stream from that cache (measured: one set of
@@ -251,6 +254,10 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     if pending is not None:
         cur.wait_event(pending[1])
         pending = None
+    elif slots_written is not None:
+        # no view of the step had record sums for the current stream to wait for: it waits for the slot bases themselves,
+        # so that their memory, once the states are dropped, is not handed out again under the kernel that writes them
+        cur.wait_event(slots_written)
     if cotangent is None:
         _front_follows(front, cur)
         return states, None, []

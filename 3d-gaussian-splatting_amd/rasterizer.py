@@ -106,7 +106,7 @@ class RenderState:
     """Everything one forward leaves behind for inspection and for the backward."""
     __slots__ = ("view", "cview", "n", "num_visible", "num_pairs", "mask_u8", "pos2d", "cov2d", "radius_full",
                  "bbox", "ntiles", "rec", "order", "slot_base", "slot_seq", "tile_offsets", "tile_order", "pair_slot", "sorted_gauss",
-                 "stream_rec", "final_T", "img", "pairgrad", "_counters", "_host", "_ready", "_slot_rest", "_slot_owner")
+                 "stream_rec", "final_T", "img", "pairgrad", "_counters", "_host", "_ready", "_slot_rest")
 
     def __init__(self):
         for s in self.__slots__:
@@ -261,21 +261,34 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, project
         st._counters, st._host, st._ready = counters, host[k], ready
         states.append(st)
     if defer_slot_base:
-        states[0]._slot_rest = (order, slot_seq, slot_base, n, nv)
+        rest = _SlotRest(order, slot_seq, slot_base, n, nv)
         for st in states:
-            st._slot_owner = states[0]
+            st._slot_rest = rest
     return states
+
+
+class _SlotRest:
+    """The deferred ``gsr_slot_bases`` call of one group of views: the whole-group arrays it takes.  Every state of the
+    group refers to this holder and the holder to no state, so dropping the states frees the arrays at once (no
+    reference cycle for the collector to find)."""
+    __slots__ = ("args",)
+
+    def __init__(self, *args):
+        self.args = args
 
 
 def forward_slot_bases(states):
     """Enqueues, on the current stream, the ``slot_base`` arrays that ``forward_begin_views(..., defer_slot_base=True)``
-    left out (once per group of views; later calls do nothing)."""
+    left out (once per group of views; later calls do nothing).  Returns whether anything was enqueued."""
+    enqueued = False
     for st in states:
-        owner, st._slot_owner = st._slot_owner, None
-        if owner is not None and owner._slot_rest is not None:
-            (order, slot_seq, slot_base, n, nv), owner._slot_rest = owner._slot_rest, None
+        rest, st._slot_rest = st._slot_rest, None
+        if rest is not None and rest.args is not None:
+            (order, slot_seq, slot_base, n, nv), rest.args = rest.args, None
             _call("gsr_slot_bases", _lib.load().gsr_slot_bases, _ptr(order), _ptr(slot_seq), n, nv, _ptr(slot_base),
                   _stream(order.device))
+            enqueued = True
+    return enqueued
 
 
 def forward_lists(st: RenderState) -> RenderState:
@@ -436,7 +449,7 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     f32 = dict(dtype=torch.float32, device=dev)
     dimg = dimg.to(torch.float32).contiguous()
     I = st.num_pairs
-    if st._slot_owner is not None:
+    if st._slot_rest is not None:
         forward_slot_bases([st])
     pairgrad = _alloc_pairgrad(lib, st, dev)
     _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T),
@@ -474,7 +487,7 @@ def backward_composite(st: RenderState, dimg) -> torch.Tensor:
 def record_sums(st: RenderState, pairgrad: torch.Tensor, gsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The per-Gaussian sums of a view's gradient records, on the current stream: gsum [N,12]."""
     lib = _lib.load()
-    if st._slot_owner is not None:
+    if st._slot_rest is not None:
         forward_slot_bases([st])
     dev = st.mask_u8.device
     if gsum is None:

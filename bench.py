@@ -338,8 +338,8 @@ def main():
             "stage_hbm_frac": dict(
                 [(k, round(ab[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
                  for k in ("preprocess_fwd", "preprocess_fwd_views", "composite_fwd", "composite_bwd", "pair_reduce") if stage_ms.get(k, 0.0) > 0.0] +
-                [("preprocess_bwd_views", round(ab["preprocess_bwd_views"] / (stage_ms["preprocess_bwd_views"] * max(len(views), 1) * 1e-3)
-                                                / 1e9 / HBM_PEAK_GBS, 4))] if stage_ms.get("preprocess_bwd_views", 0.0) > 0.0 else []),
+                ([("preprocess_bwd_views", round(ab["preprocess_bwd_views"] / (stage_ms["preprocess_bwd_views"] * max(len(views), 1) * 1e-3)
+                                                 / 1e9 / HBM_PEAK_GBS, 4))] if stage_ms.get("preprocess_bwd_views", 0.0) > 0.0 else [])),
         }
         if flops_bwd and not args.forward_only:
             # 60 flop for every pixel of every pair (what the reference's formulation costs) ...

@@ -208,7 +208,7 @@ def test_deferred_slot_bases_equal_the_ones_of_the_scan(n, w, h, deg, nviews):
     dev, params, views = _scene(n, w, h, deg, nviews)
     plain = R.forward_begin_views(*params, views)
     later = R.forward_begin_views(*params, views, defer_slot_base=True)
-    assert later[0]._slot_rest is not None and all(st._slot_owner is not None for st in later)
+    assert all(st._slot_rest is later[0]._slot_rest and st._slot_rest is not None for st in later)
     R.forward_slot_bases(later)
     R.forward_slot_bases(later)          # (a second call does nothing)
     torch.cuda.synchronize()
@@ -223,4 +223,27 @@ def test_deferred_slot_bases_equal_the_ones_of_the_scan(n, w, h, deg, nviews):
         ref = plain[-1]
         R.forward_finish(ref)
         _same(R.backward_records(st, cot), R.backward_records(ref, cot), "record sums behind the lazily run call")
-    assert st._slot_owner is None or not st.num_visible
+    assert st._slot_rest is None or not st.num_visible
+
+
+def test_forward_only_states_free_their_memory_when_dropped():
+    """A forward-only render_views defers the slot bases and never runs them; the states it returns must not keep each
+    other alive: dropping them gives the per-view arrays back at once, with Python's cyclic collector switched off."""
+    import gc
+    from gsplat_amd.minibatch import render_views
+    dev, params, views = _scene(60_000, 320, 200, 1, 4)
+    render_views(params, views, None)          # (warm-up: streams, pinned buffers, library)
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated(dev)
+        states, _, _ = render_views(params, views, None)
+        torch.cuda.synchronize()
+        held = torch.cuda.memory_allocated(dev)
+        assert held > base + 60_000 * 4 * 40          # (the N-indexed arrays of four views at least)
+        del states
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated(dev) <= base, "states dropped without a collection still hold device memory"
+    finally:
+        gc.enable()

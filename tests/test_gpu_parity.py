@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from util import GRAD_OUTLIERS, assert_bit_equal, assert_close, golden_names, load_golden
+from util import (GRAD_OUTLIERS, assert_bit_equal, assert_close, check_config1, config1_golden_names, config1_inputs, golden_names,
+                  load_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -550,3 +551,28 @@ def test_factored_sh_gradient_equals_the_single_pass():
         # accumulate adds on top
         sh_grad_views(views, p[0], p[4], list(g_all), out.sh, accumulate=True)
         assert_close(out.sh.cpu().numpy(), 2 * ref.sh.cpu().numpy(), "accumulated sh gradient")
+
+
+@pytest.mark.parametrize("name", config1_golden_names())
+def test_reference_at_config1_size(name):
+    """The reference's own CPU case at its size (50 k Gaussians, degree 0, 180 x 180, tile edge 64 - the default of
+    GaussianRenderer.py:49 - and 16): render, the loss of Trainer.py:35-38 against the reduced head photograph, backward -
+    the statements of Trainer.py:55-57 - through the C ABI, against what the reference itself produced."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.loss import loss_and_grad
+    from gsplat_amd.rasterizer import ViewSpec, backward_pipeline, forward_pipeline
+    g = load_golden(name)
+    scene, target = config1_inputs(g)
+    dev = _gpu()
+    p = [t.to(dev) for t in scene.params()]
+    view = ViewSpec(int(g["sh_degree"]), int(g["width"]), int(g["height"]), int(g["tile_length"]),
+                    tuple(g["w2m"].reshape(16).tolist()), tuple(g["proj"].reshape(16).tolist()), tuple(g["cam_pos"].tolist()))
+    st = forward_pipeline(*p, None, view)
+    out3, dimg = loss_and_grad(st.img, torch.from_numpy(target).to(dev), float(g["loss_lambda"]))
+    grads = backward_pipeline(st, *p, dimg)
+    torch.cuda.synchronize()
+    mask = st.mask_u8.bool().cpu().numpy()
+    out = dict(mask=mask, tile_offsets=st.tile_offsets.cpu().numpy().astype(np.int64),
+               tile_lists=st.sorted_gauss.cpu().numpy()[:st.num_pairs], img=st.img.cpu().numpy(),
+               radius=st.radius_full.cpu().numpy()[mask])
+    check_config1(g, out, tuple(float(x) for x in out3.cpu()), {k: v.cpu().numpy() for k, v in zip(GRADS, grads)})

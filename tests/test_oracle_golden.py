@@ -2,8 +2,8 @@
 import numpy as np
 import pytest
 
-from util import (assert_bit_equal, assert_close, assert_close_nan, golden_names, load_golden, loss_golden_names,
-                  nan_colour_golden_names, nonfinite_golden_names)
+from util import (assert_bit_equal, assert_close, assert_close_nan, check_config1, config1_golden_names, config1_inputs,
+                  golden_names, load_golden, loss_golden_names, nan_colour_golden_names, nonfinite_golden_names)
 
 GRADS = ("g_coords", "g_scale", "g_rotation", "g_opacity", "g_sh", "g_screen")
 
@@ -152,3 +152,28 @@ def test_oracle_spreads_nan_like_the_reference(oracle_mod, name):
     g = load_golden(name)
     assert np.isnan(g["sh"]).any() and np.isnan(g["opacity"]).any()
     check_nan_colour(run_oracle(oracle_mod, g), g)
+
+
+@pytest.mark.parametrize("name", config1_golden_names())
+def test_oracle_matches_reference_at_config1_size(oracle_mod, name):
+    """The reference's own CPU case at its size: 50 k Gaussians, degree 0, a 180 x 180 view, tile edges 64 (the default
+    of GaussianRenderer.py:49) and 16, the loss of Trainer.py:35-38 against a head photograph reduced by four, backward.
+    The oracle runs the same pass: render, loss oracle, backward with the loss's gradient as cotangent."""
+    g = load_golden(name)
+    scene, target = config1_inputs(g)
+    tile, lam = int(g["tile_length"]), float(g["loss_lambda"])
+    fwd = oracle_mod.render_scene(scene, tile)
+    ol = oracle_mod.loss(fwd["img"], target, 1.0 - lam, -lam)
+    o = oracle_mod.render_scene(scene, tile, dimg=ol["dpred"])
+    loss = (1.0 - lam) * ol["l1"] + lam * (1.0 - ol["ssim"])
+    check_config1(g, o, (loss, ol["l1"], ol["ssim"]), {k: o[k] for k in GRADS})
+
+
+def test_config1_fixture_coverage():
+    names = config1_golden_names()
+    assert sorted(int(load_golden(n)["tile_length"]) for n in names) == [16, 64]
+    for n in names:
+        g = load_golden(n)
+        assert int(g["n"]) == 50_000 and int(g["sh_degree"]) == 0 and g["target"].shape == (180, 180, 3)
+        assert g["target"].dtype == np.uint8 and g["target"].max() > 200        # 0..255 targets (Utils/DataLoader.py:83)
+        assert int(g["ref_tile_offsets"][-1]) > 100_000

@@ -2,11 +2,18 @@
 array inside the library) against gsr_exclusive_scan (block sums in a caller workspace), bit for bit, on
 two calls in a row - the second on a smaller input, so that what the first call left in the shared array
 must not leak into it."""
+import gc
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+def _alloc_events(dev):
+    stats = torch.cuda.memory_stats(dev)
+    return (stats.get("allocation.all.allocated", 0), stats.get("segment.all.allocated", 0))
 
 
 def _scan_both(L, lib, x):
@@ -22,14 +29,26 @@ def _scan_both(L, lib, x):
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     L.check(lib.gsr_exclusive_scan(tin.data_ptr(), out_ws.data_ptr(), n, tot_ws.data_ptr(), ws.data_ptr(), wsb, stream), "scan")
     torch.cuda.synchronize()
-    # torch's allocator must not move, and the device's free memory must not shrink (a raw hipMalloc would take
-    # some; it may grow: child processes of earlier tests can still be giving their memory back)
-    before = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev))
-    free_before = torch.cuda.mem_get_info(dev)[0]
-    L.check(lib.gsr_exclusive_scan_static(tin.data_ptr(), out_st.data_ptr(), n, tot_st.data_ptr(), stream), "scan_static")
+    # What must not happen inside the window is an ALLOCATION: torch's allocator counts its allocation and segment
+    # events (monotonic, so tensors of earlier tests that Python's collector frees meanwhile do not show), and the
+    # device's free memory must not shrink (a raw hipMalloc would take some; it may grow: child processes of earlier
+    # tests can still be giving their memory back).  The collector is run first and held off for the window.
+    gc.collect()
     torch.cuda.synchronize()
-    assert (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)) == before
-    assert torch.cuda.mem_get_info(dev)[0] >= free_before
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        before = _alloc_events(dev)
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        L.check(lib.gsr_exclusive_scan_static(tin.data_ptr(), out_st.data_ptr(), n, tot_st.data_ptr(), stream), "scan_static")
+        torch.cuda.synchronize()
+        after = _alloc_events(dev)
+        free_after = torch.cuda.mem_get_info(dev)[0]
+    finally:
+        if gc_was_on:
+            gc.enable()
+    assert after == before, f"torch allocated inside gsr_exclusive_scan_static: {before} -> {after}"
+    assert free_after >= free_before
     return out_ws.cpu().numpy()[:n], int(tot_ws.cpu()[0]), out_st.cpu().numpy()[:n], int(tot_st.cpu()[0])
 
 

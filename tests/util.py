@@ -19,8 +19,53 @@ def _names():
 
 def golden_names():
     """Fixtures of the render path (tests/golden/make_golden.py)."""
-    other = ("loss_", "adam_", "stats_", "densify_", "clone_", "split_", "remove_", "camera_")   # fixtures of the loss and of the training-state updates
+    other = ("loss_", "adam_", "stats_", "densify_", "clone_", "split_", "remove_", "camera_", "config1_")   # fixtures of the loss, of the training-state updates and of the reference's own CPU case at its size
     return [n for n in _names() if not n.startswith(other) and not n.startswith(("nonfinite_", "nancolour_"))]
+
+
+def config1_golden_names():
+    """The reference's own CPU case at its size (tests/golden/make_config1_golden.py): inputs regenerate from the seed."""
+    return [n for n in _names() if n.startswith("config1_")]
+
+
+def config1_inputs(g):
+    """The scene of a config-1 fixture, rebuilt from its seed and checked against the fixture's digest of the
+    reference run's inputs.  -> (scene, target [W,H,3] float32 0..255)"""
+    import hashlib
+
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.scenes import orbit_scene
+    scene = orbit_scene(int(g["n"]), int(g["width"]), int(g["height"]), int(g["sh_degree"]), view=int(g["view"]), n_views=8,
+                        seed=int(g["seed"]))
+    digest = hashlib.sha256(b"".join(t.numpy().tobytes() for t in scene.params())).hexdigest()
+    assert digest == str(g["inputs_sha256"]), "the seeded scene is not the one the reference rendered"
+    return scene, g["target"].astype(np.float32)
+
+
+def check_config1(g, out, loss3, grads):
+    """A render of a config-1 fixture's scene against what the reference produced: ``out`` holds mask, tile_offsets,
+    tile_lists, img, radius (length M); ``loss3`` = (loss, l1, ssim); ``grads``: the six gradients by name."""
+    import hashlib
+    n, stride = int(g["n"]), int(g["row_stride"])
+    mask = np.unpackbits(g["ref_mask_bits"])[:n].astype(bool)
+    assert_bit_equal(np.asarray(out["mask"], dtype=bool), mask, "mask")
+    assert_bit_equal(np.asarray(out["tile_offsets"], dtype=np.int64), g["ref_tile_offsets"], "tile_offsets (list lengths)")
+    digest = hashlib.sha256(np.ascontiguousarray(out["tile_lists"], dtype=np.int32).tobytes()).hexdigest()
+    assert digest == str(g["ref_tile_lists_sha256"]), "tile lists differ from the reference's"
+    assert_close(out["img"], g["ref_img"], "img")
+    assert_close(np.asarray(out["radius"])[::stride], g["ref_radius_rows"], "radius")
+    assert_close(loss3[0], g["ref_loss"], "loss", rtol=1e-5, atol_frac=0)
+    assert_close(loss3[1], g["ref_l1"], "l1", rtol=1e-5, atol_frac=0)
+    assert_close(loss3[2], g["ref_ssim"], "ssim", rtol=1e-4, atol_frac=0)
+    for k, v in grads.items():
+        rows, ref = np.asarray(v)[::stride], g["ref_" + k + "_rows"]
+        # the absolute floor refers to the largest entry of the WHOLE reference tensor, of which the fixture keeps every 16th row
+        scale = float(g["ref_" + k + "_absmax"])
+        err = np.abs(rows.astype(np.float64) - ref.astype(np.float64))
+        tol = RTOL * np.abs(ref.astype(np.float64)) + ATOL_FRAC * scale
+        assert rows.shape == ref.shape and np.array_equal(np.isnan(rows), np.isnan(ref)), k
+        bad = err > tol
+        assert not bad.any(), f"{k}: {int(bad.sum())}/{bad.size} elements outside rtol {RTOL} (+{ATOL_FRAC}*{scale:.3e}); worst {err.max():.3e}"
 
 
 def nan_colour_golden_names():
