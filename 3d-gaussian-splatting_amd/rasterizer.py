@@ -117,10 +117,14 @@ _copy_streams = {}
 _pinned_pool = []
 
 
-def _copy_stream(dev):
-    key = (dev.type, dev.index)
+def _copy_stream(dev, priority: int = 0):
+    """The stream of the counter read-backs, one per device and PRIORITY CLASS of the stream it serves: a wait of a
+    high-priority stream for work on a stream of normal priority is a priority inversion that HIP does not promise to
+    resolve (the two classes have hardware queues of their own and the scheduler prefers the higher one), so every
+    side stream is created in the class of the caller's stream."""
+    key = (dev.type, dev.index, int(priority))
     if key not in _copy_streams:
-        _copy_streams[key] = torch.cuda.Stream(device=dev)
+        _copy_streams[key] = torch.cuda.Stream(device=dev, priority=int(priority))
     return _copy_streams[key]
 
 
@@ -166,7 +170,7 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
     # and the number of pairs (stage 1 sums the tile counts) are final there, so the copy, the host's wait for it and
     # the sizing of the per-pair buffers run beside the depth sort that is enqueued next.
     main = torch.cuda.current_stream(dev)
-    side = _copy_stream(dev)
+    side = _copy_stream(dev, main.priority)
     done = torch.cuda.Event()
     done.record(main)
     st._counters = counters
@@ -234,7 +238,7 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, project
           _ptr(opac_raw), _ptr(sh), _ptr(mask), _ptr(depth_key), _ptr(pos2d), _ptr(cov2d), _ptr(radius), _ptr(bbox),
           _ptr(ntiles), _ptr(rec), _ptr(counters), stream)
     main = torch.cuda.current_stream(dev)
-    side = _copy_stream(dev)
+    side = _copy_stream(dev, main.priority)
     done = torch.cuda.Event()
     done.record(main)
     host = torch.empty(nv, 8, dtype=torch.int32, pin_memory=True)

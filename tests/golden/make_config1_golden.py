@@ -6,12 +6,15 @@ Run in the build container only (needs /root/reference):
     python tests/golden/make_config1_golden.py fixtures     # writes config1_n50000_180x180_deg0_t{64,16}.npz
     python tests/golden/make_config1_golden.py compare200k  # prints the oracle-vs-reference comparison, writes nothing
 
-``fixtures``: the imported reference renders ``orbit_scene(50_000, 180, 180, 0, view=3, seed=31)`` at tile edges 64
+``fixtures``: the imported reference renders ``orbit_scene(50_000, 180, 180, 0, view=3, seed=31)`` - its parameters
+cut to the upper 16 bits of their fp32 patterns, so that they are stored exactly in half the space (the generator's
+``pow``, ``log`` and normal draws are not reproducible bit for bit from one CPU model to the next) - at tile edges 64
 (what ``Trainer.py:55`` passes by default) and 16, the loss is the reference's ``0.8 * l1 + 0.2 * (1 - ssim)``
 (``Trainer.py:35-38`` over ``Utils/Loss.py``) against ``HumanHeadImages/head000.jpg`` read with PIL, reduced from 720 to
 180 pixels and kept as 0..255 floats (``Utils/DataLoader.py:81-83``), and ``loss.backward()`` gives the gradients.  The
-inputs regenerate from the seed; a fixture stores the target, the image, the mask bits, the tile offsets (list lengths),
-a SHA-256 of the concatenated tile lists, the loss and every 16th row of the six gradients.
+inputs are stored once (``config1_n50000_inputs.npz``: uint16 upper halves; degree 0 reads one sh coefficient per channel,
+the other fifteen are the constant 0.25); a fixture stores the target, the image, the mask bits, the tile offsets (list
+lengths), a SHA-256 of the concatenated tile lists, the loss and every 16th row of the six gradients.
 
 ``compare200k``: 200 k Gaussians, degree 3, 800 x 800, tile 16 - mask, positions with the depth key, boxes, offsets and
 lists of the oracle against the reference bit for bit, image and gradients within rtol 1e-4.  Takes about a minute and
@@ -42,8 +45,31 @@ HEAD = os.path.join(ref_harness.REF, "HumanHeadImages", "head000.jpg")
 GRADS = ("g_coords", "g_scale", "g_rotation", "g_opacity", "g_sh", "g_screen")
 
 
+def _upper16(t):
+    """fp32 values cut to the upper 16 bits of their patterns (sign, exponent, 7 fraction bits): exact in a uint16."""
+    return (t.contiguous().view(torch.int32) & -65536).view(torch.float32)
+
+
 def config1_scene():
-    return orbit_scene(N, W, H, DEG, view=VIEW, n_views=8, seed=SEED)
+    sc = orbit_scene(N, W, H, DEG, view=VIEW, n_views=8, seed=SEED)
+    sh = torch.full_like(sc.sh, 0.25)          # degree 0 reads coefficient 0 only; the rest must not matter
+    sh[:, :, 0] = _upper16(sc.sh[:, :, 0])
+    sc.coords, sc.scale, sc.rotation, sc.opacity, sc.sh = (_upper16(sc.coords), _upper16(sc.scale), _upper16(sc.rotation),
+                                                           _upper16(sc.opacity), sh)
+    return sc
+
+
+def _bits16(t):
+    return (t.contiguous().view(torch.int32) >> 16).to(torch.int16).numpy().view(np.uint16)
+
+
+def save_inputs(sc):
+    path = os.path.join(HERE, f"config1_n{N}_inputs.npz")
+    np.savez_compressed(path, coords=_bits16(sc.coords), scale=_bits16(sc.scale), rotation=_bits16(sc.rotation),
+                        opacity=_bits16(sc.opacity), sh0=_bits16(sc.sh[:, :, 0]), sh_rest=np.float32(0.25),
+                        cam_position=np.asarray(sc.cam_position, dtype=np.float64),
+                        cam_rotation=np.asarray(sc.cam_rotation, dtype=np.float64), fx=np.float64(sc.fx), fy=np.float64(sc.fy))
+    print(f"{os.path.basename(path)}: {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
 
 
 def head_target():
@@ -85,6 +111,7 @@ def reference_training_pass(scene, tile, target_u8):
 
 def make_fixtures():
     target = head_target()
+    save_inputs(config1_scene())
     for tile in (64, 16):
         scene = config1_scene()
         print(f"config 1 at tile {tile}:", flush=True)

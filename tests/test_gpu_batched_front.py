@@ -208,7 +208,7 @@ def test_deferred_slot_bases_equal_the_ones_of_the_scan(n, w, h, deg, nviews):
     dev, params, views = _scene(n, w, h, deg, nviews)
     plain = R.forward_begin_views(*params, views)
     later = R.forward_begin_views(*params, views, defer_slot_base=True)
-    assert all(st._slot_rest is later[0]._slot_rest and st._slot_rest is not None for st in later)
+    assert all(st._slot_rest is not None for st in later) and later[1]._slot_rest is later[0]._slot_rest   # (one holder per group of views)
     R.forward_slot_bases(later)
     R.forward_slot_bases(later)          # (a second call does nothing)
     torch.cuda.synchronize()
@@ -247,3 +247,31 @@ def test_forward_only_states_free_their_memory_when_dropped():
         assert torch.cuda.memory_allocated(dev) <= base, "states dropped without a collection still hold device memory"
     finally:
         gc.enable()
+
+
+def test_render_views_on_a_high_priority_stream():
+    """With a HIGH-priority stream current the side streams of the pipeline are created in that priority class (a
+    high-priority stream that waits for streams of normal priority is a priority inversion the scheduler need not
+    resolve): the pipelined step runs and its results equal the default stream's bit for bit."""
+    from gsplat_amd import minibatch
+    from gsplat_amd.minibatch import render_views
+    dev, params, views = _scene(60_000, 320, 200, 2, 4)
+    gen = torch.Generator().manual_seed(9)
+    cots = [(torch.rand(320, 200, 3, generator=gen) / 6).to(dev) for _ in views]
+    _, ref, ref_screens = render_views(params, views, lambda i, st: cots[i])
+    ref = [g.clone() for g in list(ref) + list(ref_screens)]
+    torch.cuda.synchronize()
+    high = torch.cuda.Stream(device=dev, priority=-1)
+    assert high.priority < 0
+    for step in range(3):
+        with torch.cuda.stream(high):
+            high.wait_stream(torch.cuda.default_stream(dev))
+            _, got, screens = render_views(params, views, lambda i, st: cots[i])
+            kept = [g.clone() for g in list(got) + list(screens)]
+        high.synchronize()
+        for a, b in zip(kept, ref):
+            _same(a, b, f"step {step}")
+    assert any(k[0] == "front" and k[3] < 0 for k in minibatch._side_streams)
+    with torch.cuda.stream(high):
+        render_views(params, views[:1], lambda i, st: cots[i])          # (a single view: only the read-back's side stream)
+    torch.cuda.synchronize()

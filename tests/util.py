@@ -24,21 +24,30 @@ def golden_names():
 
 
 def config1_golden_names():
-    """The reference's own CPU case at its size (tests/golden/make_config1_golden.py): inputs regenerate from the seed."""
-    return [n for n in _names() if n.startswith("config1_")]
+    """The reference's own CPU case at its size (tests/golden/make_config1_golden.py)."""
+    return [n for n in _names() if n.startswith("config1_") and not n.endswith("_inputs")]
 
 
 def config1_inputs(g):
-    """The scene of a config-1 fixture, rebuilt from its seed and checked against the fixture's digest of the
-    reference run's inputs.  -> (scene, target [W,H,3] float32 0..255)"""
+    """The scene of a config-1 fixture from the stored inputs (uint16 upper halves of the fp32 patterns), checked against
+    the fixture's digest of what the reference rendered.  -> (scene, target [W,H,3] float32 0..255)"""
     import hashlib
 
+    import torch
+
     import gsplat_amd  # noqa: F401
-    from gsplat_amd.scenes import orbit_scene
-    scene = orbit_scene(int(g["n"]), int(g["width"]), int(g["height"]), int(g["sh_degree"]), view=int(g["view"]), n_views=8,
-                        seed=int(g["seed"]))
+    from gsplat_amd.scenes import Scene
+    d = load_golden(f"config1_n{int(g['n'])}_inputs")
+
+    def f32(bits):
+        return torch.from_numpy((bits.astype(np.uint32) << 16).view(np.float32).copy())
+
+    sh = torch.full((int(g["n"]), 3, 16), float(d["sh_rest"]), dtype=torch.float32)
+    sh[:, :, 0] = f32(d["sh0"])
+    scene = Scene(f32(d["coords"]), f32(d["scale"]), f32(d["rotation"]), f32(d["opacity"]), sh, int(g["sh_degree"]),
+                  int(g["width"]), int(g["height"]), d["cam_position"], d["cam_rotation"], float(d["fx"]), float(d["fy"]))
     digest = hashlib.sha256(b"".join(t.numpy().tobytes() for t in scene.params())).hexdigest()
-    assert digest == str(g["inputs_sha256"]), "the seeded scene is not the one the reference rendered"
+    assert digest == str(g["inputs_sha256"]), "the stored inputs are not the ones the reference rendered"
     return scene, g["target"].astype(np.float32)
 
 
