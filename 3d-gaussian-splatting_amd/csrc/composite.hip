@@ -37,7 +37,8 @@ constexpr float kTinyT = 1e-26f;
 constexpr float kMinNormalT = 1.17549435e-38f;   // FLT_MIN
 constexpr float kRescue = 1099511627776.0f;      // 2^40: FLT_MIN * 2^40 > kTinyT
 // records between the L2 touch and the scalar fetch in the forward and in the backward (the forward alone is 3 %
-// faster with 8 than with 16 and slower again below 6; the backward runs the same from 2 to 16)
+// faster with 8 than with 16 and slower again below 6; the backward runs the same from 2 to 16; beside the list kernels
+// of the next view on a second stream 24 / 48 and 16 / 96 change nothing either)
 constexpr uint32_t kTouchAhead = 8, kTouchAheadBwd = 16;
 
 struct WaveGeom {
@@ -189,6 +190,14 @@ __device__ inline float clamp_alpha(float raw) { return fminf(fmaxf(raw, kAlphaM
 // per-pixel fused multiply-adds are written on pairs; a lane's 4 pixels are 2 pairs.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ inline f2 splat(float s) { return f2{s, s}; }
+// x + y of a pair with ONE plain add: left to itself the compiler writes v_pk_add_f32 with swapped halves, a packed
+// instruction (two lanes' worth of issue time) for one useful sum
+__device__ inline float hsum(f2 s)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(s.x), "v"(s.y));
+    return r;
+}
 __device__ inline f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ inline f2 exp2_2(f2 q) { return f2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)}; }
 __device__ inline f2 clamp_alpha2(f2 raw) { return f2{clamp_alpha(raw.x), clamp_alpha(raw.y)}; }
@@ -497,7 +506,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     float U = 0.0f;
     if (!CHECK) {
         const f2 ur = pk_fma(T[1], gr[1], T[0] * gr[0]), ug = pk_fma(T[1], gg[1], T[0] * gg[0]), ub = pk_fma(T[1], gb[1], T[0] * gb[0]);
-        U = reduce_full(lanes, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, ur.x + ur.y, ug.x + ug.y, ub.x + ub.y) * lanes.colour;
+        U = reduce_full(lanes, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, hsum(ur), hsum(ug), hsum(ub)) * lanes.colour;
     }
     // Sums of one entry over the lane's pixels (pairs are added up at the end).
     f2 s_vx, s_vy, s_xx, s_xy, s_yy, s_o, s_r, s_g, s_b;
@@ -591,7 +600,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
             if (CHECK) {
                 half_low(0, R, k, red, true, true);
                 half_low(1, R, k, red, false, true);
-                reduce_store_colour<MODE>(lanes, pairgrad, rec_off, gs, s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+                reduce_store_colour<MODE>(lanes, pairgrad, rec_off, gs, hsum(s_r), hsum(s_g), hsum(s_b));
             } else {
                 half_low(0, R, k, red, true, false);
                 half_low(1, R, k, red, false, false);
@@ -615,8 +624,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         }
         // (an entry that is not flagged but whose clamp blocks every pixel anyway - one in a thousand -
         // simply stores zero sums)
-        const float val = reduce_full(lanes, s_vx.x + s_vx.y, s_vy.x + s_vy.y, s_xx.x + s_xx.y, s_xy.x + s_xy.y, s_yy.x + s_yy.y, s_o.x + s_o.y,
-                                      s_r.x + s_r.y, s_g.x + s_g.y, s_b.x + s_b.y);
+        const float val = reduce_full(lanes, hsum(s_vx), hsum(s_vy), hsum(s_xx), hsum(s_xy), hsum(s_yy), hsum(s_o), hsum(s_r), hsum(s_g), hsum(s_b));
         if (!CHECK) U = fmaf(val, lanes.colour, U);
         put_record<MODE>(pairgrad, rec_off, lanes.full_off, val, kFullWriters, gs);
     };

@@ -443,7 +443,7 @@ __device__ inline void put(float *dst, float v)
 // of dependent loads in a single lane.  Both orders are fixed: the result is reproducible.
 constexpr uint32_t kHeavyTiles = 96;
 
-__device__ inline void add_record(double (&acc)[9], const float *__restrict__ pairgrad, uint32_t slot)
+__device__ inline void add_record(double (&acc)[9], const float *__restrict__ pairgrad, size_t slot)
 {
     const float4 *src = reinterpret_cast<const float4 *>(pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS);
     const float4 a = src[0], b = src[1], c = src[2];
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, uint32_t parts,
     const int lane = threadIdx.x & 63;
     const bool live = i < n && mask[i];
     const uint32_t nt = live ? ntiles[i] * parts : 0u;
-    const uint32_t e0 = live ? slot_base[i] * parts : 0u;
+    const size_t e0 = live ? (size_t)slot_base[i] * parts : 0u;   // (rows: pairs x parts may pass 2^32)
     double acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, uint32_t parts,
     while (todo) {
         const int src_lane = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const uint32_t E0 = __shfl(e0, src_lane, 64), NT = __shfl(nt, src_lane, 64);
+        const size_t E0 = ((size_t)__shfl((uint32_t)(e0 >> 32), src_lane, 64) << 32) | __shfl((uint32_t)e0, src_lane, 64);
+        const uint32_t NT = __shfl(nt, src_lane, 64);
         double part[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) part[k] = 0.0;

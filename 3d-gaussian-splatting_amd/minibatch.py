@@ -209,16 +209,26 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     states, live, gsums = [], [], []
     sums = _sums_stream(dev, prio) if front is not cur and cotangent is not None else cur
     pending = None
+    readies = {}
+
+    def lists_of(i):
+        """Enqueues the lists of view i on the front stream (once) and returns the event behind them."""
+        if i not in readies:
+            ready = None
+            with torch.cuda.stream(front):
+                R.forward_lists(begun[i])
+                if front is not cur:
+                    ready = torch.cuda.Event()
+                    ready.record(front)
+            readies[i] = ready
+        return readies[i]
+
     for i in range(len(views)):
         st = begun[i]
         if batch_lists:
             ready = lists_ready            # (the lists of all views were enqueued above)
         else:
-            with torch.cuda.stream(front):
-                R.forward_lists(st)
-                if front is not cur:
-                    ready = torch.cuda.Event()
-                    ready.record(front)
+            ready = lists_of(i)
         if i + lookahead < len(views):
             begin(i + lookahead)
         states.append(st)
