@@ -258,11 +258,20 @@ __global__ __launch_bounds__(256) void finalize_lists_kernel(
             flags = tile_all_clamped_low(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, y0, y1) ? 0xFFFFFFFFu : 0u;
         }
     }
-    // stream layout: y x D' A' | o B' r ca | g slot b flags | cbh 0 cd 0
     out[0] = make_float4(a.y, a.x, b.x, a.z);
     out[1] = make_float4(b.y, a.w, b.z, c.y);
-    out[2] = make_float4(b.w, __uint_as_float(slot), c.x, __uint_as_float(flags));
-    out[3] = make_float4(c.z, 0.0f, c.w, 0.0f);
+    if (ONE_BLOCK) {
+        // stream layout of a one-block tile: y x D' A' | o B' r ca | g slot+flags b b/100 | cbh r/100 cd g/100
+        // (the two hint bits ride above the slot, which stays below 2^26; the colour times alpha's lower clamp serves
+        // the halves on which alpha sits at that clamp: the blend adds 0.01 T colour there, GaussianRenderer.py:104-112)
+        constexpr float kAlphaFloor = 0.01f;
+        out[2] = make_float4(b.w, __uint_as_float(slot | (flags << 30)), c.x, kAlphaFloor * c.x);
+        out[3] = make_float4(c.z, kAlphaFloor * b.z, c.w, kAlphaFloor * b.w);
+    } else {
+        // stream layout of larger tiles: y x D' A' | o B' r ca | g slot b flags | cbh 0 cd 0
+        out[2] = make_float4(b.w, __uint_as_float(slot), c.x, __uint_as_float(flags));
+        out[3] = make_float4(c.z, 0.0f, c.w, 0.0f);
+    }
     const uint32_t first = p == 0 ? 0u : (packed ? (uint32_t)(sorted_owner_slot[p - 1] >> (bits.slot + bits.gauss)) : sorted_tile[p - 1]) + 1u;
     for (uint32_t t = first; t <= cur; ++t) tile_offsets[t] = p;  // tiles (prev, cur] start at p
     if (p + 1 == num_pairs)

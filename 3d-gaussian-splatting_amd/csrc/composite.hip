@@ -104,6 +104,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct Rec {
     f32x16 d;
 };
+// (two layouts, see GSR_STREAM_DWORDS in gsr.h: `ONE` = the tile is a single 16x16 block)
 #define R_gy(R) ((R).d[0])
 #define R_gx(R) ((R).d[1])
 #define R_D(R) ((R).d[2])
@@ -113,11 +114,24 @@ struct Rec {
 #define R_r(R) ((R).d[6])
 #define R_ca(R) ((R).d[7])
 #define R_g(R) ((R).d[8])
-#define R_slot(R) (__float_as_uint((R).d[9]))
 #define R_b(R) ((R).d[10])
-#define R_flags(R) (__float_as_uint((R).d[11]))
 #define R_cbh(R) ((R).d[12])
 #define R_cd(R) ((R).d[14])
+// one-block tiles: 0.01 x colour, for the halves on which alpha sits at its lower clamp
+#define R_b1(R) ((R).d[11])
+#define R_r1(R) ((R).d[13])
+#define R_g1(R) ((R).d[15])
+constexpr uint32_t kSlotBits = 30;   // one-block tiles: dword 9 = emission slot (below 2^26) | the two hint bits << 30
+template <bool ONE>
+__device__ inline uint32_t rec_slot(const f32x16 &d)
+{
+    return ONE ? __float_as_uint(d[9]) & ((1u << kSlotBits) - 1u) : __float_as_uint(d[9]);
+}
+template <bool ONE>
+__device__ inline uint32_t rec_flags(const f32x16 &d)
+{
+    return ONE ? __float_as_uint(d[9]) >> kSlotBits : __float_as_uint(d[11]);
+}
 
 // Scalar load of the record at byte offset `off` of the stream, issued now and waited for later
 // (rec_wait), so that the latency of one record's fetch (a few hundred cycles from L2) overlaps the
@@ -221,11 +235,18 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     }
 
     // alpha is 0.01 on this half of the block: no exponent, no exp
+    // (the record of a one-block tile carries 0.01 x colour for this path: the weight 0.01 T is never formed)
     auto half_low = [&](int h, const Rec &R, float red) {
-        const f2 wgt = splat(kAlphaMin) * T[h];
-        cr[h] = pk_fma(wgt, splat(red), cr[h]);
-        cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
-        cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
+        if (!MULTI) {
+            cr[h] = pk_fma(T[h], splat(R_r1(R)), cr[h]);
+            cg[h] = pk_fma(T[h], splat(R_g1(R)), cg[h]);
+            cb[h] = pk_fma(T[h], splat(R_b1(R)), cb[h]);
+        } else {
+            const f2 wgt = splat(kAlphaMin) * T[h];
+            cr[h] = pk_fma(wgt, splat(red), cr[h]);
+            cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
+            cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
+        }
         T[h] = T[h] * splat(1.0f - kAlphaMin);
         asm("" : "+v"(T[h]));   // keeps this multiply here: merged with half_full's it needs its factor in registers
     };
@@ -241,7 +262,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     };
     auto blend = [&](const Rec &R) {
         const float red = R_r(R);
-        const uint32_t flags = block_flags<MULTI>(R_flags(R), w.flag_shift);
+        const uint32_t flags = block_flags<MULTI>(rec_flags<!MULTI>(R.d), w.flag_shift);
         if (flags == kLowBoth) {
             half_low(0, R, red);
             half_low(1, R, red);
@@ -515,12 +536,23 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     // colour sums and the suffix remain; the clamp blocks every geometric gradient.
     // (`first`: the half is the first one of its entry to add to the colour sums - it sets them)
     auto half_low = [&](int h, const Rec &R, uint32_t k, float red, const bool first, const bool with_colour) {
+        // T_k = T_{k+1} / 0.99, correctly rounded (see half_full).  Two operations - the product with the rounded
+        // reciprocal, then a fused correction by the reciprocal's own rounding error - would do for one step, but their
+        // error is one-sided: the quotient of a forward product lies next to a float by construction, and over 6000
+        // clamped entries the transmittance drifts by 7e-5 (5e-6 with the exact remainder).
         const float om = 1.0f - kAlphaMin, rcp = 1.0f / (1.0f - kAlphaMin);
         const f2 t0 = T[h] * splat(rcp);
         f2 Tk = pk_fma(pk_fma(splat(-om), t0, T[h]), splat(rcp), t0);
-        f2 wgt = splat(kAlphaMin) * Tk;
-        const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(red) * gr[h]));
-        f2 suf = pk_fma(wgt, cgd, suffix[h]);
+        f2 wgt = splat(0.0f), suf;
+        if (with_colour || CHECK || MODE != kOneBlock) {
+            wgt = splat(kAlphaMin) * Tk;
+            const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(red) * gr[h]));
+            suf = pk_fma(wgt, cgd, suffix[h]);
+        } else {
+            // (0.01 x colour from the record of a one-block tile: the weight is never formed)
+            const f2 cgd1 = pk_fma(splat(R_b1(R)), gb[h], pk_fma(splat(R_g1(R)), gg[h], splat(R_r1(R)) * gr[h]));
+            suf = pk_fma(Tk, cgd1, suffix[h]);
+        }
         if (CHECK) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -593,8 +625,8 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         s_yy = first_geo ? hvy * vy : pk_fma(hvy, vy, s_yy);
     };
     auto entry = [&](const Rec &R, uint32_t k) {
-        const uint32_t rec_off = R_slot(R) * (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));   // a Gaussian's records are contiguous
-        const uint32_t flags = block_flags<MODE != kOneBlock>(R_flags(R), w.flag_shift);
+        const uint32_t rec_off = rec_slot<MODE == kOneBlock>(R.d) * (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));   // a Gaussian's records are contiguous
+        const uint32_t flags = block_flags<MODE != kOneBlock>(rec_flags<MODE == kOneBlock>(R.d), w.flag_shift);
         const float red = R_r(R);
         if (flags == kLowBoth) {
             if (CHECK) {
@@ -756,7 +788,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Tf[j] = 1.0f; Ts[j] = 0.0f; nstop[j] = len; }
         auto forward_step = [&](const Rec &R, uint32_t idx) {
-            const uint32_t bf = block_flags<MODE != kOneBlock>(R_flags(R), w.flag_shift);
+            const uint32_t bf = block_flags<MODE != kOneBlock>(rec_flags<MODE == kOneBlock>(R.d), w.flag_shift);
             const bool low[2] = {(bf & kLowTop) != 0, (bf & kLowBottom) != 0};
             const float o = R_o(R);
             const float dx = R_gx(R) - pxf;

@@ -78,7 +78,7 @@ def executed_flops_bwd(stream_rec, num_pairs):
     """Flops the compositing backward EXECUTES for one view at tile 16, from the hint flags of its record stream:
     a half block (128 pixels) whose alpha is pinned at 0.01 takes the short path (transmittance, suffix and colour
     sums: about 20 flop per pixel), any other half the full one (about 60 flop per pixel and one exp2 + one rcp)."""
-    flags = stream_rec[:num_pairs].view(torch.int32)[:, 11] & 3
+    flags = (stream_rec[:num_pairs].view(torch.int32)[:, 9] >> 30) & 3          # (one-block tiles: the hint bits ride above the slot)
     low_halves = int(((flags & 1) + ((flags >> 1) & 1)).sum().item())
     full_halves = 2 * num_pairs - low_halves
     return 128.0 * (60.0 * full_halves + 20.0 * low_halves), low_halves / max(2 * num_pairs, 1)

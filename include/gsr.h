@@ -70,6 +70,10 @@ typedef struct gsr_counters {
  * instructions sit at even dwords (an aligned register pair needs no copy):
  *   0 y   1 x   2 D'   3 A'   4 opacity   5 B'   6 r   7 a   8 g   9 slot (u32)   10 b
  *   11 flags (u32)   12 (b+c)/2   13 0   14 d   15 0
+ * When the tile is a single 16x16 block (tile_length <= 16) the two hint bits ride in dword 9 above the slot
+ * (slot | flags << 30; slots stay below 2^26) and dwords 11, 13, 15 hold b/100, r/100, g/100: the colour times the
+ * lower clamp of alpha (0.01, GaussianRenderer.py:104-105), with which the compositing kernels blend the halves on
+ * which alpha sits at that clamp - 0.01 T colour as T times these - without forming the weight.
  * slot  = the pair's emission slot (row of pairgrad its gradient record goes to);
  * flags = hints for the compositing waves: a tile of edge L is composited by S*S waves, S = ceil(L/16),
  *         one per 16x16 block (block c = bx * S + by); bits 2c / 2c+1 are set when alpha is 0.01 on

@@ -31,7 +31,8 @@ def test_flagged_halves_are_clamped_and_few_clamped_halves_are_missed(tile):
     nbh = (H + tile - 1) // tile
     off = st.tile_offsets.cpu().long()
     rec = st.stream_rec[:st.num_pairs]
-    flags_all = rec[:, 11].contiguous().view(torch.int32)
+    # (one-block tiles: the two hint bits ride above the emission slot in dword 9; larger tiles: dword 11)
+    flags_all = (rec[:, 9].contiguous().view(torch.int32) >> 30) & 3 if tile <= 16 else rec[:, 11].contiguous().view(torch.int32)
     gen = torch.Generator().manual_seed(0)
     tiles = torch.randperm(off.numel() - 1, generator=gen)[:60].tolist()
     flagged = clamped = wrong = halves = 0

@@ -1,7 +1,6 @@
 set -e
-mkdir -p gpurun_out/r3b
-for rep in 1 2; do
-GSR_REC_FLOATS_EXP=12 STEPS=10 bash tools/bench_variants.sh "rec48"
-GSR_REC_FLOATS_EXP=16 STEPS=10 bash tools/bench_variants.sh "hsum"
-done > gpurun_out/r3b/rec.txt 2>&1
-cat gpurun_out/r3b/rec.txt
+mkdir -p gpurun_out/r3c
+timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py tests/test_gpu_renderer.py tests/test_gpu_hint_flags.py tests/test_gpu_batched_front.py -x -q --timeout 120 --timeout-method thread > gpurun_out/r3c/parity.log 2>&1 || { tail -30 gpurun_out/r3c/parity.log; exit 1; }
+tail -2 gpurun_out/r3c/parity.log
+STEPS=10 bash tools/bench_variants.sh "prev base prev base" > gpurun_out/r3c/variants.txt 2>&1
+cat gpurun_out/r3c/variants.txt

@@ -22,7 +22,7 @@ def main():
     p = [t.to(dev) for t in sc.params()]
     view = ViewSpec.from_camera(sc.camera(device=dev), 3, 16)
     st = forward_pipeline(*p, None, view)
-    flags = st.stream_rec[:st.num_pairs].view(torch.int32)[:, 11].cpu().numpy() & 3
+    flags = (st.stream_rec[:st.num_pairs].view(torch.int32)[:, 9].cpu().numpy() >> 30) & 3
     off = st.tile_offsets.cpu().numpy().astype(np.int64)
     low = flags == 3
     # run starts: a low entry whose predecessor is not low or belongs to another tile
