@@ -2,6 +2,8 @@
 # Builds a variant of the library for back-to-back comparisons on one box (tools/bench_variants.sh):
 #   tools/build_variant.sh NAME "-DGSR_FOO=1 ..." [file.hip ...]   ->  var/libgsr_NAME.so
 # The named sources (default: composite.hip) are compiled with the extra flags, the other objects are the in-tree ones.
+# A variant is tied to the tree it was built from: after a change of a buffer layout (include/gsr.h constants the host
+# code allocates by) delete var/ - a stale library writes rows of the old width into buffers of the new one.
 set -e
 name=$1; flags=$2; shift 2 || true
 files=${@:-composite.hip}
