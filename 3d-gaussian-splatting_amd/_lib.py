@@ -17,6 +17,9 @@ STREAM_DWORDS = 16
 PAIRGRAD_FLOATS = 12
 MAX_VIEWS = 8
 ADAM_MAX_TENSORS = 8
+VERSION = 2
+# what gsr_version() of a library with these row widths returns (GSR_VERSION_WORD in include/gsr.h)
+VERSION_WORD = VERSION | REC_FLOATS << 8 | STREAM_DWORDS << 16 | PAIRGRAD_FLOATS << 24
 
 # Every symbol include/gsr.h declares.
 SYMBOLS = (
@@ -81,6 +84,12 @@ def load():
         if not hasattr(lib, name):
             raise RuntimeError(f"{LIB_PATH} does not export {name}")
     lib.gsr_last_error.restype = C.c_char_p
+    # The buffers are allocated here by the row widths above: a library built with other widths (a stale build, a
+    # variant of an experiment) would write rows of its own width into them - out of bounds.  Refuse it.
+    if lib.gsr_version() != VERSION_WORD:
+        raise RuntimeError(f"{LIB_PATH} reports version word {lib.gsr_version():#x}, this host code expects "
+                           f"{VERSION_WORD:#x} (version | record floats << 8 | stream dwords << 16 | gradient-record "
+                           "floats << 24): rebuild the library from this tree")
     for name in ("gsr_sort_workspace_bytes", "gsr_scan_workspace_bytes", "gsr_bin_offsets_workspace_bytes",
                  "gsr_bin_lists_workspace_bytes", "gsr_preprocess_bwd_workspace_bytes",
                  "gsr_densify_select_workspace_bytes", "gsr_remove_select_workspace_bytes",

@@ -15,7 +15,7 @@ void gsr_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *gsr_last_error(void) { return g_err; }
-extern "C" int gsr_version(void) { return 1; }
+extern "C" int gsr_version(void) { return GSR_VERSION_WORD; }
 
 int gsr_check_launch(const char *what)
 {

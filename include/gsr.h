@@ -87,6 +87,12 @@ typedef struct gsr_counters {
 #define GSR_PAIRGRAD_FLOATS 12
 
 const char *gsr_last_error(void);
+/* Version of the library in the low byte, above it the row widths the caller allocates by:
+ * GSR_VERSION | GSR_REC_FLOATS << 8 | GSR_STREAM_DWORDS << 16 | GSR_PAIRGRAD_FLOATS << 24.  A caller compiled or written
+ * against other widths must refuse the library (a library that writes rows wider than the caller allocated them
+ * writes out of bounds): compare with GSR_VERSION_WORD. */
+#define GSR_VERSION 2
+#define GSR_VERSION_WORD (GSR_VERSION | GSR_REC_FLOATS << 8 | GSR_STREAM_DWORDS << 16 | GSR_PAIRGRAD_FLOATS << 24)
 int gsr_version(void);
 
 /* ---- stage 1: per-Gaussian ------------------------------------------------------------

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), f"libgsr.so does not export {name}"
     assert set(declared_functions()) == set(_lib.SYMBOLS)
-    assert _lib.load().gsr_version() >= 1
+    assert _lib.load().gsr_version() == _lib.VERSION_WORD          # (load() itself refuses any other)
 
 
 def test_struct_layout_matches_header():
