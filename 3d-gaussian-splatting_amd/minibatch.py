@@ -74,22 +74,20 @@ class GradBucket:
 _side_streams = {}
 
 
-def _side_stream(role: str, dev, priority: int = 0):
-    """A side stream of the pipelined minibatch (``role``: "front" or "sums"), one per device and priority class: the side
-    streams are created in the class of the caller's current stream, so that no stream of the pipeline ever waits for a
-    stream of a lower class (``rasterizer._copy_stream``)."""
-    key = (role, dev.type, dev.index, int(priority))
+def _side_stream(role: str, dev):
+    """A side stream of the pipelined minibatch (``role``: "front" or "sums"), one per device."""
+    key = (role, dev.type, dev.index)
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=dev, priority=int(priority))
+        _side_streams[key] = torch.cuda.Stream(device=dev)
     return _side_streams[key]
 
 
-def _front_stream(dev, priority: int = 0):
-    return _side_stream("front", dev, priority)
+def _front_stream(dev):
+    return _side_stream("front", dev)
 
 
-def _sums_stream(dev, priority: int = 0):
-    return _side_stream("sums", dev, priority)
+def _sums_stream(dev):
+    return _side_stream("sums", dev)
 
 
 def _front_follows(front, cur):
@@ -100,11 +98,9 @@ def _front_follows(front, cur):
         front.wait_event(done)
 
 
-def reserve_streams(device=None, priority: int = 0):
+def reserve_streams(device=None):
     """Creates the three side streams of the pipelined minibatch (front part of the next views, record sums, counter read-back)
-    and runs a trivial operation on each, which binds them to hardware queues of their own.  ``priority``: the class of
-    the stream ``render_views`` will be called on (0 normal, -1 high); side streams of another class are created when
-    they are first needed.
+    and runs a trivial operation on each, which binds them to hardware queues of their own.
 
     Call this BEFORE ``torch.distributed.init_process_group("nccl", ...)``.  A process has few hardware queues
     (``GPU_MAX_HW_QUEUES``, 4 by default) and HIP hands them to streams in the order the streams are first used;
@@ -114,7 +110,7 @@ def reserve_streams(device=None, priority: int = 0):
     changed."""
     from . import rasterizer as R
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    for stream in (_front_stream(dev, priority), _sums_stream(dev, priority), R._copy_stream(dev, priority)):
+    for stream in (_front_stream(dev), _sums_stream(dev), R._copy_stream(dev)):
         with torch.cuda.stream(stream):
             torch.zeros(1, device=dev).add_(1.0)
     torch.cuda.synchronize(dev)
@@ -147,9 +143,9 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     no image), ``g_screens`` one tensor per view that had something visible."""
     from . import rasterizer as R
     dev = params[0].device
+    R.refuse_high_priority_stream(dev)
     cur = torch.cuda.current_stream(dev)
-    prio = cur.priority          # the side streams belong to the priority class of the caller's stream (see _side_stream)
-    front = _front_stream(dev, prio) if overlap and len(views) > 1 else cur
+    front = _front_stream(dev) if overlap and len(views) > 1 else cur
     if front is not cur:
         start = torch.cuda.Event()
         start.record(cur)
@@ -182,11 +178,11 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
             if sums_apart and cotangent is not None:
                 ordered = torch.cuda.Event()
                 ordered.record(front)
-                with torch.cuda.stream(_sums_stream(dev, prio)):
-                    _sums_stream(dev, prio).wait_event(ordered)
+                with torch.cuda.stream(_sums_stream(dev)):
+                    _sums_stream(dev).wait_event(ordered)
                     if R.forward_slot_bases(begun):
                         slots_written = torch.cuda.Event()
-                        slots_written.record(_sums_stream(dev, prio))
+                        slots_written.record(_sums_stream(dev))
             # The lists of all views with one set of launches as well - when the record streams of all views together
             # stay inside the GPU's last-level cache.  Larger ones are better built view by view, right before the
             # view is composited: the forward then reads most of its stream from that cache (measured: one set of
@@ -207,7 +203,7 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
     for i in range(len(begun), min(max(lookahead, 1), len(views))):
         begin(i)
     states, live, gsums = [], [], []
-    sums = _sums_stream(dev, prio) if front is not cur and cotangent is not None else cur
+    sums = _sums_stream(dev) if front is not cur and cotangent is not None else cur
     pending = None
     readies = {}
 

@@ -117,15 +117,23 @@ _copy_streams = {}
 _pinned_pool = []
 
 
-def _copy_stream(dev, priority: int = 0):
-    """The stream of the counter read-backs, one per device and PRIORITY CLASS of the stream it serves: a wait of a
-    high-priority stream for work on a stream of normal priority is a priority inversion that HIP does not promise to
-    resolve (the two classes have hardware queues of their own and the scheduler prefers the higher one), so every
-    side stream is created in the class of the caller's stream."""
-    key = (dev.type, dev.index, int(priority))
+def _copy_stream(dev):
+    key = (dev.type, dev.index)
     if key not in _copy_streams:
-        _copy_streams[key] = torch.cuda.Stream(device=dev, priority=int(priority))
+        _copy_streams[key] = torch.cuda.Stream(device=dev)
     return _copy_streams[key]
+
+
+def refuse_high_priority_stream(dev):
+    """Raises when a HIGH-priority stream is current.  Every render hands work to side streams (the counter read-back;
+    in a view minibatch the list building and the record sums) and waits for them.  With the caller's stream in the
+    high-priority class those waits stalled for good: with side streams of normal priority in the one run that tried it
+    (a stream of the high class waiting for queues of the lower class is a priority inversion the queue scheduler need not
+    resolve), and with side streams created in the high class as well in one run out of three.  HIP gives no progress
+    guarantee to lean on here, so the case is refused instead of left to hang."""
+    if torch.cuda.current_stream(dev).priority < 0:
+        raise RuntimeError("a high-priority stream is current: the render path synchronises with side streams of normal "
+                           "priority and does not run on a high-priority stream (use a stream of default priority)")
 
 
 def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec) -> RenderState:
@@ -138,6 +146,7 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
     dev = coords.device
     n = coords.shape[0]
     coords = _check_param("coords", coords, (3,))
+    refuse_high_priority_stream(dev)
     scale_raw = _check_param("scale", scale_raw, (3,), n)
     rot_raw = _check_param("rotation", rot_raw, (4,), n)
     if opac_raw.dim() == 1:
@@ -170,7 +179,7 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
     # and the number of pairs (stage 1 sums the tile counts) are final there, so the copy, the host's wait for it and
     # the sizing of the per-pair buffers run beside the depth sort that is enqueued next.
     main = torch.cuda.current_stream(dev)
-    side = _copy_stream(dev, main.priority)
+    side = _copy_stream(dev)
     done = torch.cuda.Event()
     done.record(main)
     st._counters = counters
@@ -214,6 +223,7 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, project
     n = coords.shape[0]
     nv = len(views)
     coords = _check_param("coords", coords, (3,))
+    refuse_high_priority_stream(dev)
     scale_raw = _check_param("scale", scale_raw, (3,), n)
     rot_raw = _check_param("rotation", rot_raw, (4,), n)
     if opac_raw.dim() == 1:
@@ -238,7 +248,7 @@ def forward_begin_views(coords, scale_raw, rot_raw, opac_raw, sh, views, project
           _ptr(opac_raw), _ptr(sh), _ptr(mask), _ptr(depth_key), _ptr(pos2d), _ptr(cov2d), _ptr(radius), _ptr(bbox),
           _ptr(ntiles), _ptr(rec), _ptr(counters), stream)
     main = torch.cuda.current_stream(dev)
-    side = _copy_stream(dev, main.priority)
+    side = _copy_stream(dev)
     done = torch.cuda.Event()
     done.record(main)
     host = torch.empty(nv, 8, dtype=torch.int32, pin_memory=True)

@@ -249,29 +249,21 @@ def test_forward_only_states_free_their_memory_when_dropped():
         gc.enable()
 
 
-def test_render_views_on_a_high_priority_stream():
-    """With a HIGH-priority stream current the side streams of the pipeline are created in that priority class (a
-    high-priority stream that waits for streams of normal priority is a priority inversion the scheduler need not
-    resolve): the pipelined step runs and its results equal the default stream's bit for bit."""
-    from gsplat_amd import minibatch
+def test_a_high_priority_stream_is_refused():
+    """The render path hands work to side streams and waits for them; with a HIGH-priority stream current those waits can
+    stall for good, so the call is refused before anything is enqueued - by ``render_views`` and by the one-view path."""
+    from gsplat_amd import rasterizer as R
     from gsplat_amd.minibatch import render_views
-    dev, params, views = _scene(60_000, 320, 200, 2, 4)
-    gen = torch.Generator().manual_seed(9)
-    cots = [(torch.rand(320, 200, 3, generator=gen) / 6).to(dev) for _ in views]
-    _, ref, ref_screens = render_views(params, views, lambda i, st: cots[i])
-    ref = [g.clone() for g in list(ref) + list(ref_screens)]
-    torch.cuda.synchronize()
+    dev, params, views = _scene(3000, 200, 120, 1, 2)
     high = torch.cuda.Stream(device=dev, priority=-1)
     assert high.priority < 0
-    for step in range(3):
-        with torch.cuda.stream(high):
-            high.wait_stream(torch.cuda.default_stream(dev))
-            _, got, screens = render_views(params, views, lambda i, st: cots[i])
-            kept = [g.clone() for g in list(got) + list(screens)]
-        high.synchronize()
-        for a, b in zip(kept, ref):
-            _same(a, b, f"step {step}")
-    assert any(k[0] == "front" and k[3] < 0 for k in minibatch._side_streams)
     with torch.cuda.stream(high):
-        render_views(params, views[:1], lambda i, st: cots[i])          # (a single view: only the read-back's side stream)
+        with pytest.raises(RuntimeError, match="high-priority stream"):
+            render_views(params, views, None)
+        with pytest.raises(RuntimeError, match="high-priority stream"):
+            render_views(params, views, None, overlap=False)
+        with pytest.raises(RuntimeError, match="high-priority stream"):
+            R.forward_begin(*params, None, views[0])
+    states, _, _ = render_views(params, views, None)          # (the default stream still works afterwards)
     torch.cuda.synchronize()
+    assert all(st.num_visible for st in states)
