@@ -160,7 +160,7 @@ def render_views(params: Sequence[torch.Tensor], views: Sequence, cotangent: Opt
 
     def begin(i):
         with torch.cuda.stream(front):
-            begun.append(R.forward_begin(*params, None, views[i]))
+            begun.append(R.forward_begin(*params, None, views[i], projection=False))      # (nothing here reads pos2d / cov2d)
 
     lists_ready = None
     batch_lists = False

@@ -136,12 +136,14 @@ def refuse_high_priority_stream(dev):
                            "priority and does not run on a high-priority stream (use a stream of default priority)")
 
 
-def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec) -> RenderState:
+def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view: ViewSpec, projection: bool = True) -> RenderState:
     """Stage 1 and the depth order of one view, plus an asynchronous read-back of the three counters
     (visible Gaussians, pairs, error) on a side stream.  Nothing here waits for the GPU, so a caller
     with several views can enqueue this part for all of them before it calls ``forward_finish`` on
     the first: the counters of the later views are then long on the host when they are needed and the
-    GPU never idles on a round trip."""
+    GPU never idles on a round trip.  ``projection=False`` (only without ``screen_coords``): ``pos2d`` and ``cov2d``,
+    which nothing after stage 1 reads, are not written (28 bytes per Gaussian less, through the kernel that serves the
+    view minibatches); everything else is the same bit for bit."""
     lib = _lib.load()
     dev = coords.device
     n = coords.shape[0]
@@ -164,17 +166,23 @@ def forward_begin(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, view:
     f32 = dict(dtype=torch.float32, device=dev)
     st.mask_u8 = torch.empty(n, dtype=torch.uint8, device=dev)
     depth_key = torch.empty(n, **i32)
-    st.pos2d = torch.empty(n, 3, **f32)
-    st.cov2d = torch.empty(n, 4, **f32)
+    lean = not projection and screen_coords is None
+    st.pos2d = None if lean else torch.empty(n, 3, **f32)
+    st.cov2d = None if lean else torch.empty(n, 4, **f32)
     st.radius_full = torch.empty(n, **f32)
     st.bbox = torch.empty(n, 4, **i32)
     st.ntiles = torch.empty(n, **i32)
     st.rec = torch.empty(n, _lib.REC_FLOATS, **f32)
     counters = torch.zeros(8, **i32)
-    _call("gsr_preprocess_fwd", lib.gsr_preprocess_fwd, cv, _ptr(coords), _ptr(scale_raw), _ptr(rot_raw), _ptr(opac_raw), _ptr(sh),
-                                      _ptr(screen_coords), _ptr(st.mask_u8), _ptr(depth_key), _ptr(st.pos2d),
-                                      _ptr(st.cov2d), _ptr(st.radius_full), _ptr(st.bbox), _ptr(st.ntiles),
-                                      _ptr(st.rec), _ptr(counters), stream)
+    if lean:
+        _call("gsr_preprocess_fwd_views", lib.gsr_preprocess_fwd_views, (_lib.GsrView * 1)(cv), 1, _ptr(coords), _ptr(scale_raw),
+              _ptr(rot_raw), _ptr(opac_raw), _ptr(sh), _ptr(st.mask_u8), _ptr(depth_key), None, None, _ptr(st.radius_full),
+              _ptr(st.bbox), _ptr(st.ntiles), _ptr(st.rec), _ptr(counters), stream)
+    else:
+        _call("gsr_preprocess_fwd", lib.gsr_preprocess_fwd, cv, _ptr(coords), _ptr(scale_raw), _ptr(rot_raw), _ptr(opac_raw), _ptr(sh),
+              _ptr(screen_coords), _ptr(st.mask_u8), _ptr(depth_key), _ptr(st.pos2d),
+              _ptr(st.cov2d), _ptr(st.radius_full), _ptr(st.bbox), _ptr(st.ntiles),
+              _ptr(st.rec), _ptr(counters), stream)
     # Read the counters back on a side stream, right behind stage 1: the number of visible Gaussians, the error word
     # and the number of pairs (stage 1 sums the tile counts) are final there, so the copy, the host's wait for it and
     # the sizing of the per-pair buffers run beside the depth sort that is enqueued next.

@@ -267,3 +267,23 @@ def test_a_high_priority_stream_is_refused():
     states, _, _ = render_views(params, views, None)          # (the default stream still works afterwards)
     torch.cuda.synchronize()
     assert all(st.num_visible for st in states)
+
+
+@pytest.mark.parametrize("n,w,h,deg", [(3000, 200, 120, 3), (70_001, 640, 360, 2), (5, 64, 48, 0)])
+def test_one_view_without_projection_outputs_equals_the_full_one(n, w, h, deg):
+    """``forward_begin(..., projection=False)`` - what ``render_views`` uses for a rank with a single view - goes through the
+    kernel of the view minibatches with one view and leaves everything but ``pos2d`` / ``cov2d``, bit for bit."""
+    from gsplat_amd import rasterizer as R
+    dev, params, views = _scene(n, w, h, deg, 1)
+    full = R.forward_begin(*params, None, views[0])
+    lean = R.forward_begin(*params, None, views[0], projection=False)
+    R.forward_finish(full)
+    R.forward_finish(lean)
+    assert lean.pos2d is None and lean.cov2d is None
+    assert (lean.num_visible, lean.num_pairs) == (full.num_visible, full.num_pairs)
+    for f in FIELDS:
+        if f not in ("pos2d", "cov2d"):
+            _same(getattr(lean, f), getattr(full, f), f)
+    if full.num_visible:
+        for f in ("tile_offsets", "img", "final_T"):
+            _same(getattr(lean, f), getattr(full, f), f)
