@@ -164,6 +164,9 @@ __device__ inline void sh_basis(int deg, float x, float y, float z, float b[16])
 // d(sum_k co[k] basis_k)/d(x,y,z)
 __device__ inline void sh_dir_grad(int deg, float x, float y, float z, const float co[16], float d[3])
 {
+    // (only the backward uses this: nothing discrete depends on its roundings, so multiply-adds may fuse here although the
+    // file is compiled with contraction off for the forward's sake)
+#pragma clang fp contract(fast)
     d[0] = d[1] = d[2] = 0.0f;
     if (deg < 1) return;
     d[1] += -kC1 * co[1]; d[2] += kC1 * co[2]; d[0] += -kC1 * co[3];
@@ -549,9 +552,15 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const bool write_sh = g_sh != nullptr;
     float4 *dsh = reinterpret_cast<float4 *>(g_sh + (size_t)i * 48);
 
-    bool any = false;
-    for (int vv = 0; vv < a.nv; ++vv) any |= a.mask[vv][i] != 0;
-    if (!any) {
+    // The thread's loads are issued ahead of their use wherever the data allows it - the visibility bytes of all views
+    // at once, the sums of view v + 1 while view v is chained, the colour gradient of view v + 1 while view v's basis is
+    // evaluated: with one dependent load after the other (mask, then sums, then arithmetic, view by view, three more
+    // times for the colours) the kernel waited out some thirty memory latencies per Gaussian at three waves per SIMD.
+    uint32_t seen = 0;
+#pragma unroll
+    for (int vv = 0; vv < kMaxViews; ++vv)
+        if (vv < a.nv) seen |= (a.mask[vv][i] != 0 ? 1u : 0u) << vv;
+    if (!seen) {
         // Culled in every view: a zero cotangent, but the reference's autograd still divides it by the
         // clip-space w and multiplies it by the clip coordinates (the backward of Utils/Camera.py:103), so
         // coordinates that are not finite - which is why such a Gaussian is culled - give a NaN coordinate
@@ -584,16 +593,26 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         double dS[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};   // dL/d(cov3), summed over the views
         double d_o = 0.0;
 
+        float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;      // the sums of the next view
+        auto fetch_sums = [&](int vv) {
+            if (vv < a.nv && ((seen >> vv) & 1u)) {
+                const float4 *gsrc = reinterpret_cast<const float4 *>(a.gsum[vv] + (size_t)i * 12);
+                n0 = gsrc[0]; n1 = gsrc[1];
+            }
+        };
+        fetch_sums(0);
         for (int vv = 0; vv < a.nv; ++vv) {
             float gsc[2] = {0.f, 0.f};
-            if (a.mask[vv][i]) {
+            const float4 s0 = n0, s1 = n1;
+            fetch_sums(vv + 1);
+            if ((seen >> vv) & 1u) {
+                // (the chain below is the backward's own arithmetic: multiply-adds may fuse)
+#pragma clang fp contract(fast)
                 const ViewCam &cam = a.cam[vv];
                 // With h = -2 dL/d(exponent) per pixel, d = centre - pixel, C = inv(cov2) (symmetric part) and
                 // v = C d, the summed records hold: sum h v_x, sum h v_y, sum h v_x^2, sum h v_x v_y,
                 // sum h v_y^2, dL/d(opacity), dL/d(colour).  exponent = d^T C d, so
                 //   dL/d(centre) = sum (-h/2) (2 v) = -sum h v,   dL/d(cov2) = sum (-h/2) (-v v^T) = 1/2 sum h v v^T.
-                const float4 *gsrc = reinterpret_cast<const float4 *>(a.gsum[vv] + (size_t)i * 12);
-                const float4 s0 = gsrc[0], s1 = gsrc[1];
                 const double d_px = -(double)s0.x, d_py = -(double)s0.y;
                 const double D[2][2] = {{0.5 * (double)s0.z, 0.5 * (double)s0.w}, {0.5 * (double)s0.w, 0.5 * (double)s1.x}};
                 d_o += (double)s1.y;
@@ -686,12 +705,18 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+                float d_next = 0.0f;                  // the colour gradient of the next view
+                auto fetch_col = [&](int vv) {
+                    if (vv < a.nv && ((seen >> vv) & 1u)) d_next = a.gsum[vv][(size_t)i * 12 + 6 + ch];
+                };
+                fetch_col(0);
                 for (int vv = 0; vv < a.nv; ++vv) {
-                    if (!a.mask[vv][i]) {
+                    const float d_col = d_next;
+                    fetch_col(vv + 1);
+                    if (!((seen >> vv) & 1u)) {
                         if (a.g_color[vv]) a.g_color[vv][3 * (size_t)i + ch] = 0.0f;
                         continue;
                     }
-                    const float d_col = a.gsum[vv][(size_t)i * 12 + 6 + ch];
                     if (a.g_color[vv]) a.g_color[vv][3 * (size_t)i + ch] = d_col;
                     const float dx = p[0] - a.cam[vv].cam[0], dy = p[1] - a.cam[vv].cam[1], dz = p[2] - a.cam[vv].cam[2];
                     float bs[16];
@@ -709,7 +734,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                         gp[2] += (double)d_col * (double)dd[2];
 #pragma unroll
                         for (int k = 0; k < 16; ++k)
-                            if (k < K) acc[k] += d_col * bs[k];
+                            if (k < K) acc[k] = __fmaf_rn(d_col, bs[k], acc[k]);
                     }
                 }
 #pragma unroll
@@ -729,6 +754,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             }
         }
         {
+#pragma clang fp contract(fast)
             // cov3 = RS RS^T, RS = R diag(s), s = exp(raw), R = R(q), q = raw / max(|raw|, eps)
             double dRS[3][3], dR[3][3], ds[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -831,7 +857,7 @@ __global__ __launch_bounds__(256) void sh_grad_views_kernel(ShViews a, int n, in
             if (t >= 0.0f) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    if (k < K) acc[k] += d_col * bs[k];
+                    if (k < K) acc[k] = __fmaf_rn(d_col, bs[k], acc[k]);
             }
         }
 #pragma unroll
