@@ -25,6 +25,8 @@ python tools/pmc_summary.py $out/pmc/pass2 composite >> $out/pmc_composite_sq.tx
 python tools/pmc_all_kernels.py $out/pmc/pass1 $out/pmc/pass2 > $out/pmc_all_kernels.txt
 timeout -k 10 200 python bench.py --no-cpu-baseline --tile 64 > $out/tile64_line.json 2>/dev/null
 timeout -k 10 200 python bench.py --no-cpu-baseline --views 1 --steps 20 > $out/views1_line.json 2>/dev/null
+timeout -k 10 200 python bench.py --no-cpu-baseline --views 2 --steps 20 > $out/views2_line.json 2>/dev/null
+timeout -k 10 200 python bench.py --no-cpu-baseline --views 4 --steps 10 > $out/views4_line.json 2>/dev/null
 timeout -k 10 200 python bench.py --no-cpu-baseline --no-overlap > $out/one_stream_line.json 2>/dev/null
 timeout -k 10 200 python bench.py --no-cpu-baseline --train-iter > $out/train_iter_line.json 2>/dev/null
 timeout -k 10 200 bash tools/bench_dist1.sh > $out/one_rank_rccl_line.json 2>/dev/null
