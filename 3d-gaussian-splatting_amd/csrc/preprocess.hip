@@ -444,15 +444,19 @@ __device__ inline void put(float *dst, float v)
 // thread per Gaussian walks its slots in order; a Gaussian with many tiles is summed by the whole
 // wave (strided partial sums, then a fixed butterfly), so one huge splat cannot serialise thousands
 // of dependent loads in a single lane.  Both orders are fixed: the result is reproducible.
-constexpr uint32_t kHeavyTiles = 96;
+constexpr uint32_t kHeavyTiles = 48;   // (96: 0.079 ms, 32: 0.077, 48: 0.076 ms per view with the two-record turns below)
+
+__device__ inline void add_values(double (&acc)[9], const float4 a, const float4 b, const float4 c)
+{
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    acc[8] += ((double)c.x + (double)c.y) + ((double)c.z + (double)c.w);   // blue arrives as four partial sums
+}
 
 __device__ inline void add_record(double (&acc)[9], const float *__restrict__ pairgrad, size_t slot)
 {
     const float4 *src = reinterpret_cast<const float4 *>(pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS);
-    const float4 a = src[0], b = src[1], c = src[2];
-    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-    acc[8] += ((double)c.x + (double)c.y) + ((double)c.z + (double)c.w);   // blue arrives as four partial sums
+    add_values(acc, src[0], src[1], src[2]);
 }
 
 // Four lanes per Gaussian: lane q of the four takes the records q, q+4, ... of its Gaussian (neighbouring
@@ -461,7 +465,7 @@ __device__ inline void add_record(double (&acc)[9], const float *__restrict__ pa
 // memory latency: a Gaussian has five records on average.
 // (Walking the Gaussians in depth order, in which their records are consecutive in memory, was
 // measured slower than index order: the scattered 48-byte result rows cost more than the reads gain.)
-constexpr int kLanesPerGaussian = 4;   // (8 measured slower: 0.088 ms against 0.078 ms)
+constexpr int kLanesPerGaussian = 4;   // (8 measured slower: 0.088 ms against 0.078 ms; 2 the same as 4)
 // parts: rows of pairgrad per (tile, Gaussian) pair (gsr_pairgrad_parts): the rows of a Gaussian's pairs are
 // contiguous, parts * ntiles of them from row parts * slot_base, and are added in row order.
 __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, uint32_t parts, const uint8_t *__restrict__ mask,
@@ -480,8 +484,23 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(int n, uint32_t parts,
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
     const bool heavy = nt >= kHeavyTiles;
-    if (!heavy)
-        for (uint32_t j = (uint32_t)q; j < nt; j += kLanesPerGaussian) add_record(acc, pairgrad, e0 + j);
+    if (!heavy) {
+        constexpr int kTurn = 2;
+        uint32_t j = (uint32_t)q;
+        // kTurn records per turn, all their loads issued before the first add (the sums keep their order): 0.085 ->
+        // 0.077 ms per view; three or four per turn are slower again (0.100 ms: registers)
+        for (; j + (kTurn - 1) * kLanesPerGaussian < nt; j += kTurn * kLanesPerGaussian) {
+            float4 a[kTurn], b[kTurn], c[kTurn];
+#pragma unroll
+            for (int u = 0; u < kTurn; ++u) {
+                const float4 *src = reinterpret_cast<const float4 *>(pairgrad + (e0 + j + u * kLanesPerGaussian) * GSR_PAIRGRAD_FLOATS);
+                a[u] = src[0]; b[u] = src[1]; c[u] = src[2];
+            }
+#pragma unroll
+            for (int u = 0; u < kTurn; ++u) add_values(acc, a[u], b[u], c[u]);
+        }
+        for (; j < nt; j += kLanesPerGaussian) add_record(acc, pairgrad, e0 + j);
+    }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
 #pragma unroll
