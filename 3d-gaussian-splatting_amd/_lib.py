@@ -32,6 +32,8 @@ SYMBOLS = (
     "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order", "gsr_bin_lists_views_supported",
     "gsr_bin_lists_views_layout", "gsr_bin_lists_views_workspace_bytes", "gsr_bin_lists_views",
     "gsr_composite_fwd", "gsr_composite_bwd", "gsr_pairgrad_parts",
+    "gsr_block_lists_supported", "gsr_block_count", "gsr_block_lists_workspace_bytes", "gsr_block_lists",
+    "gsr_composite_blocks_fwd", "gsr_composite_blocks_bwd", "gsr_block_rows_reduce",
     "gsr_loss_workspace_bytes", "gsr_loss_fwd_bwd",
     "gsr_adam_step", "gsr_knn_dist2",
     "gsr_densify_stats", "gsr_densify_stats_views", "gsr_densify_select_workspace_bytes", "gsr_densify_select", "gsr_densify_apply",
@@ -125,6 +127,15 @@ def load():
     lib.gsr_bin_lists_views_workspace_bytes.argtypes = [C.c_uint32, u32p]
     lib.gsr_bin_lists_views.argtypes = [C.POINTER(GsrView), C.c_uint32] + [vp] * 6 + [u32p] + [vp] * 5 + [C.c_size_t, vp]
     lib.gsr_composite_fwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, vp]
+    lib.gsr_block_lists_supported.argtypes = [C.POINTER(GsrView), C.c_uint32]
+    lib.gsr_block_count.restype = C.c_uint32
+    lib.gsr_block_count.argtypes = [C.POINTER(GsrView)]
+    lib.gsr_block_lists_workspace_bytes.restype = C.c_size_t
+    lib.gsr_block_lists_workspace_bytes.argtypes = [C.POINTER(GsrView), C.c_uint32]
+    lib.gsr_block_lists.argtypes = [C.POINTER(GsrView), vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.gsr_composite_blocks_fwd.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, vp, vp, vp, vp]
+    lib.gsr_composite_blocks_bwd.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_block_rows_reduce.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.gsr_composite_bwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, C.c_uint32, vp, vp]
     lib.gsr_loss_workspace_bytes.restype = C.c_size_t
     lib.gsr_loss_workspace_bytes.argtypes = [C.c_int, C.c_int]

@@ -1,0 +1,394 @@
+// Per-block lists for tiles of 2x2, 3x3 or 4x4 blocks (tile edges 32, 48, 64 - the reference's default is 64,
+// GaussianRenderer.py:49).
+//
+// The reference blends the WHOLE list of a tile into every pixel of the tile (GaussianRenderer.py:100-112), and alpha is
+// clamped from below at 0.01, so a Gaussian that does not reach a 16x16 block of its tile still contributes there:
+// alpha = 0.01 on every pixel of the block, the same for all of them.  At a tile edge of 64 that is 89 % of the entries a
+// block walks, in runs of nine.  A run of n such entries is one affine map of the block's state,
+//     T <- T * 0.99^n,      colour <- colour + T * sum_i 0.99^i * 0.01 * c_i,
+// whose two constants do not depend on the pixel.  This file turns the list of a tile into one COMPACT stream per block:
+// the entries the block has to evaluate keep their 64-byte record (in the layout of a one-block tile), every run of
+// entries that are clamped on the whole block becomes ONE record that carries the two constants.  The compositing
+// kernels of one-block tiles then walk these streams (composite.hip, `RUNS`), a fifth of the records.
+//
+// Runs end at multiples of 64 list positions (a wave handles 64 consecutive entries of a tile on its own), so the
+// kernels below need no carries between waves.
+//
+// Outputs, for a view of T16 = ceil(W/16) * ceil(H/16) blocks (block id = Y16 + ceil(H/16) * X16, the tile id of the
+// same view at a tile edge of 16):
+//   block_offsets[T16 + 1]  range of each block's records in block_stream
+//   block_stream[R, 16]     the records; a full record names its gradient row p * S^2 + c (p: position of the entry in
+//                           the tile lists, c: block inside the tile), a run record its own index
+//   combo[I * S^2]          per list position p and block c: 0xFFFFFFFF = the block evaluates the entry (a gradient row
+//                           exists), 0xFFFFFFFE = the block lies outside the image, else run << 6 | index inside the run
+#include "gsr_common.hpp"
+
+namespace {
+
+constexpr uint32_t kChunk = 64;
+constexpr uint32_t kEvaluated = 0xFFFFFFFFu, kOutside = 0xFFFFFFFEu;
+constexpr float kAlphaFloor = 0.01f;
+
+struct BlockGrid {
+    int S, S2, nbw16, nbh16, T16;
+};
+__host__ __device__ inline BlockGrid block_grid(const ViewK &v)
+{
+    BlockGrid g;
+    g.S = v.L / 16;
+    g.S2 = g.S * g.S;
+    g.nbw16 = (v.W + 15) / 16;
+    g.nbh16 = (v.H + 15) / 16;
+    g.T16 = g.nbw16 * g.nbh16;
+    return g;
+}
+
+// exclusive scan of f(0..n-1) into out[0..n] by one workgroup of 1024 threads
+template <class F>
+__device__ inline void workgroup_scan(F f, uint32_t n, uint32_t *__restrict__ out, uint32_t *s)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t begin = min(tid * per, n), end = min(begin + per, n);
+    uint32_t sum = 0;
+    for (uint32_t i = begin; i < end; ++i) sum += f(i);
+    s[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t t = tid >= d ? s[tid - d] : 0u;
+        __syncthreads();
+        s[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = s[tid] - sum;
+    for (uint32_t i = begin; i < end; ++i) { out[i] = run; run += f(i); }
+    if (tid == 1023u) out[n] = s[1023];
+    __syncthreads();
+}
+
+// chunks of 64 list positions: per tile (chunk_base_tile[T + 1]) and per block, in block-id order
+// (chunk_base_block[T16 + 1]; a block has the chunks of its tile)
+__global__ __launch_bounds__(1024) void chunk_bases_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
+                                                           uint32_t *__restrict__ chunk_base_tile,
+                                                           uint32_t *__restrict__ chunk_base_block)
+{
+    __shared__ uint32_t s[1024];
+    const BlockGrid g = block_grid(v);
+    auto chunks_of_tile = [&](uint32_t t) { return (tile_offsets[t + 1] - tile_offsets[t] + kChunk - 1u) / kChunk; };
+    workgroup_scan(chunks_of_tile, (uint32_t)v.T, chunk_base_tile, s);
+    auto chunks_of_block = [&](uint32_t b) {
+        const int X16 = (int)b / g.nbh16, Y16 = (int)b - X16 * g.nbh16;
+        return chunks_of_tile((uint32_t)((Y16 / g.S) + v.nbh * (X16 / g.S)));
+    };
+    workgroup_scan(chunks_of_block, (uint32_t)g.T16, chunk_base_block, s);
+}
+
+// the wave's chunk: tile t, chunk k of it
+__device__ inline bool wave_chunk(const ViewK &v, const uint32_t *__restrict__ chunk_base_tile, uint32_t &t, uint32_t &k)
+{
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (w >= chunk_base_tile[v.T]) return false;
+    uint32_t lo = 0, hi = (uint32_t)v.T;       // first index with chunk_base_tile[idx] > w lies in (lo, hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk_base_tile[mid] <= w) lo = mid; else hi = mid;
+    }
+    t = lo;
+    k = w - chunk_base_tile[lo];
+    return true;
+}
+
+struct BlockOfTile {
+    bool inside;
+    uint32_t id;   // block id in the image's 16-pixel grid
+};
+__device__ inline BlockOfTile block_of_tile(const ViewK &v, const BlockGrid &g, uint32_t t, int c)
+{
+    const int xi = (int)t / v.nbh, yi = (int)t - xi * v.nbh;
+    const int bx = c / g.S, by = c - bx * g.S;
+    const int X16 = xi * g.S + bx, Y16 = yi * g.S + by;
+    BlockOfTile b;
+    b.inside = X16 < g.nbw16 && Y16 < g.nbh16;
+    b.id = (uint32_t)(Y16 + g.nbh16 * X16);
+    return b;
+}
+
+// lanes that leave a record in the block's stream: every evaluated entry, and the last entry of every run
+__device__ inline unsigned long long emitters(bool valid, bool clamped, int lane)
+{
+    const unsigned long long cm = __ballot(clamped);
+    const bool next_clamped = lane < 63 && ((cm >> (lane + 1)) & 1ull);
+    return __ballot(valid && (!clamped || !next_clamped));
+}
+
+__global__ __launch_bounds__(256) void block_count_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
+                                                          const float *__restrict__ stream_rec,
+                                                          const uint32_t *__restrict__ chunk_base_tile,
+                                                          const uint32_t *__restrict__ chunk_base_block,
+                                                          uint32_t *__restrict__ counts)
+{
+    uint32_t t, k;
+    if (!wave_chunk(v, chunk_base_tile, t, k)) return;
+    const BlockGrid g = block_grid(v);
+    const int lane = threadIdx.x & 63;
+    const uint32_t p = tile_offsets[t] + k * kChunk + (uint32_t)lane;
+    const bool valid = p < tile_offsets[t + 1];
+    const uint32_t flags = valid ? __float_as_uint(stream_rec[(size_t)p * GSR_STREAM_DWORDS + 11]) : 0u;
+    // lane c keeps the count of block c and stores it after the loop (one dependent load per wave, not one per block)
+    const BlockOfTile own = block_of_tile(v, g, t, min(lane, g.S2 - 1));
+    const bool owner = lane < g.S2 && own.inside;
+    const uint32_t own_at = owner ? chunk_base_block[own.id] + k : 0u;
+    uint32_t own_count = 0;
+    for (int c = 0; c < g.S2; ++c) {
+        const bool clamped = valid && ((flags >> (2 * c)) & 3u) == 3u;
+        const unsigned long long em = emitters(valid, clamped, lane);
+        if (lane == c) own_count = (uint32_t)__popcll(em);
+    }
+    if (owner) counts[own_at] = own_count;
+}
+
+// 0.99^n and sum_i 0.99^i 0.01 c_i over the entries of the run up to this lane.  The power is kept in double and
+// rounded once: a product of rounded float factors has the same error for every run of the same length, and over the
+// few hundred runs of a list that adds up (2e-5 of the transmittance at a tile edge of 64) instead of averaging out
+// as the roundings of the entry-by-entry product do.
+struct RunSums {
+    double P;
+    float r, g, b;
+};
+
+__global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
+                                                          const float *__restrict__ stream_rec,
+                                                          const uint32_t *__restrict__ chunk_base_tile,
+                                                          const uint32_t *__restrict__ chunk_base_block,
+                                                          const uint32_t *__restrict__ first_record,   // scanned counts
+                                                          float *__restrict__ block_stream, uint32_t *__restrict__ combo)
+{
+    uint32_t t, k;
+    if (!wave_chunk(v, chunk_base_tile, t, k)) return;
+    const BlockGrid g = block_grid(v);
+    const int lane = threadIdx.x & 63;
+    const uint32_t p = tile_offsets[t] + k * kChunk + (uint32_t)lane;
+    const bool valid = p < tile_offsets[t + 1];
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
+    if (valid) {
+        const float4 *src = reinterpret_cast<const float4 *>(stream_rec + (size_t)p * GSR_STREAM_DWORDS);
+        q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];   // y x D' A' | o B' r ca | g slot b flags | cbh 0 cd 0
+    }
+    const uint32_t flags = __float_as_uint(q2.w);
+    const float red = q1.z, green = q2.x, blue = q2.z;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // lane c fetches where block c's records of this chunk start (one dependent load per wave, not one per block)
+    const BlockOfTile own = block_of_tile(v, g, t, min(lane, g.S2 - 1));
+    const uint32_t own_first = (lane < g.S2 && own.inside) ? first_record[chunk_base_block[own.id] + k] : 0u;
+    for (int c = 0; c < g.S2; ++c) {
+        const BlockOfTile b = block_of_tile(v, g, t, c);
+        const size_t at = (size_t)p * (size_t)g.S2 + (size_t)c;
+        const uint32_t first = (uint32_t)__shfl((int)own_first, c, 64);
+        if (!b.inside) {
+            if (valid) combo[at] = kOutside;
+            continue;
+        }
+        const uint32_t f = (flags >> (2 * c)) & 3u;
+        const bool clamped = valid && f == 3u;
+        const unsigned long long cm = __ballot(clamped);
+        const unsigned long long em = emitters(valid, clamped, lane);
+        const uint32_t rid = first + (uint32_t)__popcll(em & below);
+        // index of the lane inside its run: distance to the nearest lane at or below it that starts a run
+        const unsigned long long heads = cm & ~(cm << 1);
+        const unsigned long long mine = heads & (below | (1ull << lane));
+        const int idx = clamped ? lane - (63 - __clzll((long long)mine)) : 0;
+        // inclusive scan inside the run of the maps (T, C) -> (0.99 T, C + T 0.01 c): (P1, C1) then (P2, C2) is
+        // (P1 P2, C1 + P1 C2)
+        RunSums s = {(double)(1.0f - kAlphaFloor), kAlphaFloor * red, kAlphaFloor * green, kAlphaFloor * blue};
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double P1 = __shfl_up(s.P, d, 64);
+            const float r1 = __shfl_up(s.r, d, 64), g1 = __shfl_up(s.g, d, 64), b1 = __shfl_up(s.b, d, 64);
+            if (idx >= d) {
+                const float P1f = (float)P1;
+                s.r = fmaf(P1f, s.r, r1); s.g = fmaf(P1f, s.g, g1); s.b = fmaf(P1f, s.b, b1);
+                s.P = P1 * s.P;
+            }
+        }
+        if (!valid) continue;
+        float4 *dst = reinterpret_cast<float4 *>(block_stream + (size_t)rid * GSR_STREAM_DWORDS);
+        if (!clamped) {
+            // the entry's own record in the layout of a one-block tile: ... | g row+flags b b/100 | cbh r/100 cd g/100
+            const uint32_t row = (uint32_t)at;
+            dst[0] = q0; dst[1] = q1;
+            dst[2] = make_float4(green, __uint_as_float(row | (f << 30)), blue, kAlphaFloor * blue);
+            dst[3] = make_float4(q3.x, kAlphaFloor * red, q3.z, kAlphaFloor * green);
+            combo[at] = kEvaluated;
+        } else {
+            combo[at] = (rid << 6) | (uint32_t)idx;
+            const bool last = lane == 63 || !((cm >> (lane + 1)) & 1ull);
+            if (last) {
+                // a run: dword 4 = 0.99^n, dword 5 = its reciprocal, dword 9 = the record's own index (its row of the run
+                // sums) with both hint bits set, dwords 11, 13, 15 = the run's colour (blue, red, green)
+                dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float P = (float)s.P;
+                dst[1] = make_float4(P, 1.0f / P, 0.f, 0.f);
+                dst[2] = make_float4(0.f, __uint_as_float(rid | (3u << 30)), 0.f, s.b);
+                dst[3] = make_float4(0.f, s.r, 0.f, s.g);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void block_offsets_kernel(uint32_t T16, const uint32_t *__restrict__ chunk_base_block,
+                                                            const uint32_t *__restrict__ first_record,
+                                                            const uint32_t *__restrict__ total, uint32_t *__restrict__ block_offsets)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > T16) return;
+    const uint32_t i = chunk_base_block[b];
+    block_offsets[b] = i < chunk_base_block[T16] ? first_record[i] : *total;
+}
+
+// One gradient record per pair from what the blocks of its tile left: the rows of the blocks that evaluated the entry
+// (rows[p S^2 + c], written by the compositing backward), and for the blocks on which the entry was part of a run the
+// colour gradient 0.01 * 0.99^i * U, U = the run's sum over the block's pixels of (transmittance in front of the run) x
+// (cotangent), which the backward stored in run_sums[run] (red, green, four partial sums of blue).
+// Sixteen lanes per pair, one per block; their values meet in a fixed butterfly, so the result is reproducible.
+__global__ __launch_bounds__(256) void block_rows_reduce_kernel(int S2, uint32_t num_pairs, const float *__restrict__ stream_rec,
+                                                                const uint32_t *__restrict__ combo,
+                                                                const float *__restrict__ rows, const float *__restrict__ run_sums,
+                                                                float *__restrict__ pairgrad)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = tid >> 4;
+    const int c = (int)(tid & 15u);
+    const bool pair = p < num_pairs;
+    float val[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) val[j] = 0.0f;
+    if (pair && c < S2) {
+        const size_t at = (size_t)p * (size_t)S2 + (size_t)c;
+        const uint32_t m = combo[at];
+        if (m == kEvaluated) {
+            const float4 *src = reinterpret_cast<const float4 *>(rows + at * GSR_PAIRGRAD_FLOATS);
+            const float4 a = src[0], b = src[1], d = src[2];
+            val[0] = a.x; val[1] = a.y; val[2] = a.z; val[3] = a.w;
+            val[4] = b.x; val[5] = b.y; val[6] = b.z; val[7] = b.w;
+            val[8] = (d.x + d.y) + (d.z + d.w);
+        } else if (m != kOutside) {
+            const float4 *src = reinterpret_cast<const float4 *>(run_sums + (size_t)(m >> 6) * 8);
+            const float4 a = src[0], b = src[1];                       // r g b0 b1 | b2 b3 - -
+            const float wgt = kAlphaFloor * __builtin_amdgcn_exp2f((float)(m & 63u) * -0.014499569695115089f);   // 0.01 * 0.99^i
+            val[6] = wgt * a.x;
+            val[7] = wgt * a.y;
+            val[8] = wgt * ((a.z + a.w) + (b.x + b.y));
+        }
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) val[j] += __shfl_xor(val[j], d, 16);
+    }
+    if (pair && c < 3) {
+        const uint32_t slot = __float_as_uint(stream_rec[(size_t)p * GSR_STREAM_DWORDS + 9]);
+        float4 *dst = reinterpret_cast<float4 *>(pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS);
+        dst[c] = c == 0 ? make_float4(val[0], val[1], val[2], val[3])
+                        : (c == 1 ? make_float4(val[4], val[5], val[6], val[7]) : make_float4(val[8], 0.f, 0.f, 0.f));
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+    uint32_t n_counts;
+    size_t off_tile, off_block, off_counts, off_total, off_scan, scan_bytes, bytes;
+};
+inline Layout layout_of(const ViewK &v, uint32_t num_pairs)
+{
+    const BlockGrid g = block_grid(v);
+    Layout l;
+    // every block of a tile has the tile's chunks: at most S^2 (pairs / 64 + tiles) counts
+    l.n_counts = (uint32_t)g.S2 * (num_pairs / kChunk + (uint32_t)v.T) + 1u;
+    l.off_tile = 0;
+    l.off_block = l.off_tile + align256(((size_t)v.T + 1) * 4);
+    l.off_counts = l.off_block + align256(((size_t)g.T16 + 1) * 4);
+    l.off_total = l.off_counts + align256((size_t)l.n_counts * 4);
+    l.off_scan = l.off_total + 256;
+    l.scan_bytes = gsr_scan_workspace_bytes(l.n_counts);
+    l.bytes = l.off_scan + align256(l.scan_bytes);
+    return l;
+}
+
+}  // namespace
+
+extern "C" int gsr_block_lists_supported(const gsr_view *view_host, uint32_t num_pairs)
+{
+    if (!view_host) return 0;
+    const int L = view_host->tile_length;
+    if (!(L == 32 || L == 48 || L == 64)) return 0;
+    const unsigned long long S2 = (unsigned long long)(L / 16) * (unsigned long long)(L / 16);
+    // rows and records are numbered in 26 bits (a run's index rides above six bits of its entries' positions, and the
+    // record stream of the blocks must stay below 4 GiB)
+    return (unsigned long long)num_pairs * S2 < (1ull << 26) ? 1 : 0;
+}
+
+extern "C" uint32_t gsr_block_count(const gsr_view *view_host)
+{
+    return view_host ? (uint32_t)(((view_host->width + 15) / 16) * ((view_host->height + 15) / 16)) : 0u;
+}
+
+extern "C" size_t gsr_block_lists_workspace_bytes(const gsr_view *view_host, uint32_t num_pairs)
+{
+    ViewK v;
+    if (gsr_make_view(view_host, &v)) return 0;
+    return layout_of(v, num_pairs).bytes;
+}
+
+extern "C" int gsr_block_lists(const gsr_view *view_host, const uint32_t *tile_offsets, const float *stream_rec, uint32_t num_pairs,
+                               uint32_t *block_offsets, float *block_stream, uint32_t *combo, void *workspace,
+                               size_t workspace_bytes, void *stream)
+{
+    ViewK v;
+    if (int e = gsr_make_view(view_host, &v)) return e;
+    if (!gsr_block_lists_supported(view_host, num_pairs)) {
+        gsr_set_error("gsr_block_lists: tile edge %d with %u pairs is not supported (edges 32, 48, 64; pairs x blocks per tile < 2^26)",
+                      view_host->tile_length, num_pairs);
+        return GSR_ERR_ARG;
+    }
+    if (!tile_offsets || !stream_rec || !block_offsets || !block_stream || !combo || !workspace) {
+        gsr_set_error("gsr_block_lists: null pointer");
+        return GSR_ERR_ARG;
+    }
+    const Layout l = layout_of(v, num_pairs);
+    if (workspace_bytes < l.bytes) { gsr_set_error("gsr_block_lists: workspace too small"); return GSR_ERR_ARG; }
+    const BlockGrid g = block_grid(v);
+    char *ws = static_cast<char *>(workspace);
+    uint32_t *chunk_base_tile = reinterpret_cast<uint32_t *>(ws + l.off_tile);
+    uint32_t *chunk_base_block = reinterpret_cast<uint32_t *>(ws + l.off_block);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(ws + l.off_counts);
+    uint32_t *total = reinterpret_cast<uint32_t *>(ws + l.off_total);
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(counts, 0, (size_t)l.n_counts * 4, s);
+    hipLaunchKernelGGL(chunk_bases_kernel, dim3(1), dim3(1024), 0, s, v, tile_offsets, chunk_base_tile, chunk_base_block);
+    const unsigned waves = num_pairs / kChunk + (unsigned)v.T;   // at least the chunks of all tiles
+    hipLaunchKernelGGL(block_count_kernel, dim3(gsr_div_up(waves, 4)), dim3(256), 0, s, v, tile_offsets, stream_rec, chunk_base_tile,
+                       chunk_base_block, counts);
+    if (int e = gsr_exclusive_scan(counts, counts, l.n_counts, total, ws + l.off_scan, l.scan_bytes, stream)) return e;
+    hipLaunchKernelGGL(block_write_kernel, dim3(gsr_div_up(waves, 4)), dim3(256), 0, s, v, tile_offsets, stream_rec, chunk_base_tile,
+                       chunk_base_block, counts, block_stream, combo);
+    hipLaunchKernelGGL(block_offsets_kernel, dim3(gsr_div_up((unsigned)g.T16 + 1u, 256)), dim3(256), 0, s, (uint32_t)g.T16,
+                       chunk_base_block, counts, total, block_offsets);
+    return gsr_check_launch("block_lists");
+}
+
+extern "C" int gsr_block_rows_reduce(const gsr_view *view_host, uint32_t num_pairs, const float *stream_rec, const uint32_t *combo,
+                                     const float *rows, const float *run_sums, float *pairgrad, void *stream)
+{
+    ViewK v;
+    if (int e = gsr_make_view(view_host, &v)) return e;
+    if (num_pairs == 0) return GSR_OK;
+    if (!gsr_block_lists_supported(view_host, num_pairs) || !stream_rec || !combo || !rows || !run_sums || !pairgrad) {
+        gsr_set_error("gsr_block_rows_reduce: bad arguments");
+        return GSR_ERR_ARG;
+    }
+    const BlockGrid g = block_grid(v);
+    hipLaunchKernelGGL(block_rows_reduce_kernel, dim3(gsr_div_up(num_pairs, 16)), dim3(256), 0, (hipStream_t)stream, g.S2, num_pairs,
+                       stream_rec, combo, rows, run_sums, pairgrad);
+    return gsr_check_launch("block_rows_reduce");
+}

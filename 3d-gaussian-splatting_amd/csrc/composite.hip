@@ -121,6 +121,9 @@ struct Rec {
 #define R_b1(R) ((R).d[11])
 #define R_r1(R) ((R).d[13])
 #define R_g1(R) ((R).d[15])
+// run records of per-block streams (blocklists.hip): 0.99^n and its reciprocal
+#define R_P(R) ((R).d[4])
+#define R_rcpP(R) ((R).d[5])
 constexpr uint32_t kSlotBits = 30;   // one-block tiles: dword 9 = emission slot (below 2^26) | the two hint bits << 30
 template <bool ONE>
 __device__ inline uint32_t rec_slot(const f32x16 &d)
@@ -216,7 +219,10 @@ __device__ inline f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma
 __device__ inline f2 exp2_2(f2 q) { return f2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)}; }
 __device__ inline f2 clamp_alpha2(f2 raw) { return f2{clamp_alpha(raw.x), clamp_alpha(raw.y)}; }
 
-template <bool MULTI>
+// RUNS: the lists are the per-block streams of blocklists.hip - one-block layout, and a record with both hint bits set
+// stands for a run of entries clamped on the whole block: transmittance times 0.99^n (dword 4), colour plus
+// transmittance times the run's colour (dwords 11, 13, 15)
+template <bool MULTI, bool RUNS = false>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                             const uint32_t *__restrict__ tile_order,
                                                             const float *__restrict__ stream_rec,
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
 
     // alpha is 0.01 on this half of the block: no exponent, no exp
     // (the record of a one-block tile carries 0.01 x colour for this path: the weight 0.01 T is never formed)
-    auto half_low = [&](int h, const Rec &R, float red) {
+    auto half_low = [&](int h, const Rec &R, float red, float keep) {
         if (!MULTI) {
             cr[h] = pk_fma(T[h], splat(R_r1(R)), cr[h]);
             cg[h] = pk_fma(T[h], splat(R_g1(R)), cg[h]);
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
             cg[h] = pk_fma(wgt, splat(R_g(R)), cg[h]);
             cb[h] = pk_fma(wgt, splat(R_b(R)), cb[h]);
         }
-        T[h] = T[h] * splat(1.0f - kAlphaMin);
+        T[h] = T[h] * splat(keep);
         asm("" : "+v"(T[h]));   // keeps this multiply here: merged with half_full's it needs its factor in registers
     };
     auto half_full = [&](int h, const Rec &R, float red, float o, float bdx, float adx2) {
@@ -263,17 +269,19 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
     auto blend = [&](const Rec &R) {
         const float red = R_r(R);
         const uint32_t flags = block_flags<MULTI>(rec_flags<!MULTI>(R.d), w.flag_shift);
+        constexpr float keep1 = 1.0f - kAlphaMin;
         if (flags == kLowBoth) {
-            half_low(0, R, red);
-            half_low(1, R, red);
+            const float keep = RUNS ? R_P(R) : keep1;
+            half_low(0, R, red, keep);
+            half_low(1, R, red, keep);
             return;
         }
         const float o = R_o(R);
         const float dx = R_gx(R) - pxf;
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
-        if (flags & kLowTop) half_low(0, R, red); else half_full(0, R, red, o, bdx, adx2);
-        if (flags & kLowBottom) half_low(1, R, red); else half_full(1, R, red, o, bdx, adx2);
+        if (flags & kLowTop) half_low(0, R, red, keep1); else half_full(0, R, red, o, bdx, adx2);
+        if (flags & kLowBottom) half_low(1, R, red, keep1); else half_full(1, R, red, o, bdx, adx2);
     };
     // even lanes touch the record named, odd lanes the one before it; the named record is never the stream's
     // first one unless the stream has no other (touch_floor)
@@ -408,7 +416,13 @@ __device__ inline RecordLanes record_lanes(int lane)
 //               the per-Gaussian sums add them in row order.  No atomics: the result does not depend on timing.
 //               (Small workgroups, several per compute unit: while one waits at its barrier the others run.)
 //   kAtomic:    more than 16 blocks per tile: independent waves add into a zeroed pairgrad with float atomics.
-enum StoreMode { kOneBlock = 0, kAtomic = 1, kTileGroup = 2 };
+//   kBlockRuns: the per-block streams of blocklists.hip: as kOneBlock, the record of an evaluated entry goes to the row its
+//               stream record names; a run record stores the run's colour sums (six floats) in its row of `run_sums`.
+enum StoreMode { kOneBlock = 0, kAtomic = 1, kTileGroup = 2, kBlockRuns = 3 };
+constexpr bool one_block_layout(int mode) { return mode == kOneBlock || mode == kBlockRuns; }
+// the lanes of kFullWriters that hold a colour float of a full record (floats 6..11: lanes 48, 56 and 1, 17, 33, 49)
+constexpr unsigned long long kRunWriters = (1ull << 48) | (1ull << 56) | (1ull << 1) | (1ull << 17) | (1ull << 33) | (1ull << 49);
+constexpr uint32_t kRunSumFloats = 8;   // red, green, four partial sums of blue, two unused
 constexpr uint32_t kGroupChunk = 32;   // entries between two reductions of a tile group (two chunk buffers; 16 to 64 time alike)
 constexpr uint32_t kGroupMaxWaves = 4;
 
@@ -511,7 +525,7 @@ template <bool CHECK, int MODE>
 __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ stream_rec, const float pxf,
                                  const f2 (&pyf)[2], f2 (&T)[2], const f2 (&gr)[2], const f2 (&gg)[2],
                                  const f2 (&gb)[2], const uint32_t (&nstop)[4],
-                                 float *__restrict__ pairgrad, GroupSlot gs)
+                                 float *__restrict__ pairgrad, float *__restrict__ run_sums, GroupSlot gs)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
     const f2 py_top = pyf[0];
@@ -535,16 +549,22 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     // One half of the block with alpha = 0.01 on every pixel: only the transmittance recurrence, the
     // colour sums and the suffix remain; the clamp blocks every geometric gradient.
     // (`first`: the half is the first one of its entry to add to the colour sums - it sets them)
-    auto half_low = [&](int h, const Rec &R, uint32_t k, float red, const bool first, const bool with_colour) {
+    // (`run`: the record is a run of clamped entries - its 0.99^n and reciprocal instead of 0.99, its colour instead of
+    // 0.01 x colour, and `wgt` is the transmittance in front of the run)
+    auto half_low = [&](int h, const Rec &R, uint32_t k, float red, const bool first, const bool with_colour, const bool run) {
         // T_k = T_{k+1} / 0.99, correctly rounded (see half_full).  Two operations - the product with the rounded
         // reciprocal, then a fused correction by the reciprocal's own rounding error - would do for one step, but their
         // error is one-sided: the quotient of a forward product lies next to a float by construction, and over 6000
         // clamped entries the transmittance drifts by 7e-5 (5e-6 with the exact remainder).
-        const float om = 1.0f - kAlphaMin, rcp = 1.0f / (1.0f - kAlphaMin);
+        const float om = run ? R_P(R) : 1.0f - kAlphaMin, rcp = run ? R_rcpP(R) : 1.0f / (1.0f - kAlphaMin);
         const f2 t0 = T[h] * splat(rcp);
         f2 Tk = pk_fma(pk_fma(splat(-om), t0, T[h]), splat(rcp), t0);
         f2 wgt = splat(0.0f), suf;
-        if (with_colour || CHECK || MODE != kOneBlock) {
+        if (run) {
+            wgt = Tk;
+            const f2 cgd1 = pk_fma(splat(R_b1(R)), gb[h], pk_fma(splat(R_g1(R)), gg[h], splat(R_r1(R)) * gr[h]));
+            suf = pk_fma(Tk, cgd1, suffix[h]);
+        } else if (with_colour || CHECK || MODE != kOneBlock) {
             wgt = splat(kAlphaMin) * Tk;
             const f2 cgd = pk_fma(splat(R_b(R)), gb[h], pk_fma(splat(R_g(R)), gg[h], splat(red) * gr[h]));
             suf = pk_fma(wgt, cgd, suffix[h]);
@@ -625,17 +645,33 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         s_yy = first_geo ? hvy * vy : pk_fma(hvy, vy, s_yy);
     };
     auto entry = [&](const Rec &R, uint32_t k) {
-        const uint32_t rec_off = rec_slot<MODE == kOneBlock>(R.d) * (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));   // a Gaussian's records are contiguous
-        const uint32_t flags = block_flags<MODE != kOneBlock>(rec_flags<MODE == kOneBlock>(R.d), w.flag_shift);
+        const uint32_t rec_off = rec_slot<one_block_layout(MODE)>(R.d) * (uint32_t)(GSR_PAIRGRAD_FLOATS * sizeof(float));   // a Gaussian's records are contiguous
+        const uint32_t flags = block_flags<!one_block_layout(MODE)>(rec_flags<one_block_layout(MODE)>(R.d), w.flag_shift);
         const float red = R_r(R);
+        if (MODE == kBlockRuns && flags == kLowBoth) {
+            // a run: U in front of it = U behind it / 0.99^n; the entries' colour gradients follow from it elsewhere
+            const uint32_t run_off = rec_slot<true>(R.d) * (uint32_t)(kRunSumFloats * sizeof(float));
+            if (CHECK) {
+                half_low(0, R, k, red, true, true, true);
+                half_low(1, R, k, red, false, true, true);
+                const float val = reduce_full(lanes, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, hsum(s_r), hsum(s_g), hsum(s_b));
+                put_record<kOneBlock>(run_sums, run_off, lanes.full_off - 24u, val, kRunWriters, gs);
+            } else {
+                half_low(0, R, k, red, true, false, true);
+                half_low(1, R, k, red, false, false, true);
+                U = U * R_rcpP(R);
+                put_record<kOneBlock>(run_sums, run_off, lanes.full_off - 24u, U, kRunWriters, gs);
+            }
+            return;
+        }
         if (flags == kLowBoth) {
             if (CHECK) {
-                half_low(0, R, k, red, true, true);
-                half_low(1, R, k, red, false, true);
+                half_low(0, R, k, red, true, true, false);
+                half_low(1, R, k, red, false, true, false);
                 reduce_store_colour<MODE>(lanes, pairgrad, rec_off, gs, hsum(s_r), hsum(s_g), hsum(s_b));
             } else {
-                half_low(0, R, k, red, true, false);
-                half_low(1, R, k, red, false, false);
+                half_low(0, R, k, red, true, false, false);
+                half_low(1, R, k, red, false, false, false);
                 // (legacy multiply: 0 * x = 0 whatever x is, so the six geometric floats of the record are zeros even when a
                 // NaN of a diverged model has reached U on the lanes that do not hold a colour sum)
                 put_record<MODE>(pairgrad, rec_off, lanes.full_off, mul_zero_wins(U, low_gain), kFullWriters, gs);
@@ -648,11 +684,11 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         const float adx2 = R_A(R) * dx * dx;
         const float bdx = R_B(R) * dx;
         if (flags & kLowTop) {
-            half_low(0, R, k, red, true, true);
+            half_low(0, R, k, red, true, true, false);
             half_full(1, R, k, red, o, dx, adx2, bdx, false, true);   // (not both halves are flagged here)
         } else {
             half_full(0, R, k, red, o, dx, adx2, bdx, true, true);
-            if (flags & kLowBottom) half_low(1, R, k, red, false, true); else half_full(1, R, k, red, o, dx, adx2, bdx, false, false);
+            if (flags & kLowBottom) half_low(1, R, k, red, false, true, false); else half_full(1, R, k, red, o, dx, adx2, bdx, false, false);
         }
         // (an entry that is not flagged but whose clamp blocks every pixel anyway - one in a thousand -
         // simply stores zero sums)
@@ -671,7 +707,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     Rec A, B;
     const uint32_t n = w.end - w.begin;
     rec_request(stream_rec, off, A);
-    if (!CHECK && MODE == kOneBlock) {
+    if (!CHECK && one_block_layout(MODE)) {
         // plain sweep of a one-block tile: four record buffers, two fetches in flight per wait (see composite_fwd_kernel)
         auto back = [&](uint32_t records) { return max(off, off_first + records * 64u) - records * 64u; };   // (the first record again past the front)
         Rec C, D;
@@ -742,7 +778,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                                                             const float *__restrict__ stream_rec,
                                                             const float *__restrict__ final_T,
                                                             const float *__restrict__ dimg,
-                                                            float *__restrict__ pairgrad)
+                                                            float *__restrict__ pairgrad, float *__restrict__ run_sums)
 {
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
@@ -788,8 +824,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Tf[j] = 1.0f; Ts[j] = 0.0f; nstop[j] = len; }
         auto forward_step = [&](const Rec &R, uint32_t idx) {
-            const uint32_t bf = block_flags<MODE != kOneBlock>(rec_flags<MODE == kOneBlock>(R.d), w.flag_shift);
+            const uint32_t bf = block_flags<!one_block_layout(MODE)>(rec_flags<one_block_layout(MODE)>(R.d), w.flag_shift);
             const bool low[2] = {(bf & kLowTop) != 0, (bf & kLowBottom) != 0};
+            const bool run = MODE == kBlockRuns && bf == kLowBoth;
             const float o = R_o(R);
             const float dx = R_gx(R) - pxf;
             const float adx2 = R_A(R) * dx * dx;
@@ -799,7 +836,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const float dy = R_gy(R) - pyf[j >> 1][j & 1];
                 const float q = fmaf(fmaf(R_D(R), dy, bdx), dy, adx2);
                 const float a = low[j >> 1] ? kAlphaMin : clamp_alpha(o * __builtin_amdgcn_exp2f(q));
-                Tf[j] = Tf[j] * (1.0f - a);
+                Tf[j] = Tf[j] * (run ? R_P(R) : 1.0f - a);
                 const bool hit = (Tf[j] < kTinyT) && (nstop[j] == len);
                 nstop[j] = hit ? (idx + 1u) : nstop[j];
                 Ts[j] = hit ? Tf[j] : Ts[j];
@@ -836,7 +873,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             const bool inside = w.vx && (w.y0 + 4 * j) < w.ylim;
             if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
-        bwd_sweep<true, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, gs);
+        bwd_sweep<true, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, run_sums, gs);
     } else {
         // Between kTinyT and the smallest normal number the plain sweep still works on a transmittance
         // scaled up by a power of two (exact).  Everything the sweep accumulates is a product of one
@@ -849,7 +886,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 gr[h] = gr[h] * splat(1.0f / kRescue); gg[h] = gg[h] * splat(1.0f / kRescue); gb[h] = gb[h] * splat(1.0f / kRescue);
             }
         }
-        bwd_sweep<false, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, gs);
+        bwd_sweep<false, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, run_sums, gs);
     }
 }
 
@@ -899,15 +936,56 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
     if (S > 4) {
         (void)hipMemsetAsync(pairgrad, 0, (size_t)num_pairs * GSR_PAIRGRAD_FLOATS * sizeof(float), (hipStream_t)stream);
         hipLaunchKernelGGL((composite_bwd_kernel<kAtomic>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
-                           stream_rec, final_T, dimg, pairgrad);
+                           stream_rec, final_T, dimg, pairgrad, (float *)nullptr);
     } else if (S > 1) {
         // S * S / group_waves(S) workgroups per tile, one wave per block of the tile
         const int G = group_waves(S);
         hipLaunchKernelGGL((composite_bwd_kernel<kTileGroup>), dim3((unsigned)v.T * (unsigned)(S * S / G)), dim3(64 * G), 0,
-                           (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, final_T, dimg, pairgrad);
+                           (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, final_T, dimg, pairgrad, (float *)nullptr);
     } else {
         hipLaunchKernelGGL((composite_bwd_kernel<kOneBlock>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
-                           stream_rec, final_T, dimg, pairgrad);
+                           stream_rec, final_T, dimg, pairgrad, (float *)nullptr);
     }
     return gsr_check_launch("composite_bwd");
+}
+
+// The compositing kernels of one-block tiles over the per-block streams of gsr_block_lists: `view_host` is the view
+// at ITS tile edge (32, 48 or 64), the kernels run on its grid of 16-pixel blocks.
+static int blocks_view(const gsr_view *view_host, uint32_t num_pairs, ViewK *v, const char *who)
+{
+    if (!view_host || !gsr_block_lists_supported(view_host, num_pairs)) {
+        gsr_set_error("%s: the view has no per-block lists (tile edges 32, 48, 64; pairs x blocks per tile < 2^26)", who);
+        return GSR_ERR_ARG;
+    }
+    gsr_view v16 = *view_host;
+    v16.tile_length = 16;
+    return gsr_make_view(&v16, v);
+}
+
+extern "C" int gsr_composite_blocks_fwd(const gsr_view *view_host, uint32_t num_pairs, const uint32_t *block_offsets,
+                                        const uint32_t *block_order, const float *block_stream, float *img, float *final_T,
+                                        void *stream)
+{
+    ViewK v;
+    if (int e = blocks_view(view_host, num_pairs, &v, "gsr_composite_blocks_fwd")) return e;
+    if (!block_offsets || !block_stream || !img || !final_T) { gsr_set_error("gsr_composite_blocks_fwd: null pointer"); return GSR_ERR_ARG; }
+    hipLaunchKernelGGL((composite_fwd_kernel<false, true>), dim3(gsr_div_up((unsigned)v.T, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
+                       (hipStream_t)stream, v, block_offsets, block_order, block_stream, img, final_T);
+    return gsr_check_launch("composite_blocks_fwd");
+}
+
+extern "C" int gsr_composite_blocks_bwd(const gsr_view *view_host, uint32_t num_pairs, const uint32_t *block_offsets,
+                                        const uint32_t *block_order, const float *block_stream, const float *final_T,
+                                        const float *dimg, float *rows, float *run_sums, void *stream)
+{
+    ViewK v;
+    if (int e = blocks_view(view_host, num_pairs, &v, "gsr_composite_blocks_bwd")) return e;
+    if (num_pairs == 0) return GSR_OK;
+    if (!block_offsets || !block_stream || !final_T || !dimg || !rows || !run_sums) {
+        gsr_set_error("gsr_composite_blocks_bwd: null pointer");
+        return GSR_ERR_ARG;
+    }
+    hipLaunchKernelGGL((composite_bwd_kernel<kBlockRuns>), dim3(gsr_div_up((unsigned)v.T, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
+                       (hipStream_t)stream, v, block_offsets, block_order, block_stream, final_T, dimg, rows, run_sums);
+    return gsr_check_launch("composite_blocks_bwd");
 }

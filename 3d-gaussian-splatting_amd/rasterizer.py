@@ -106,7 +106,7 @@ class RenderState:
     """Everything one forward leaves behind for inspection and for the backward."""
     __slots__ = ("view", "cview", "n", "num_visible", "num_pairs", "mask_u8", "pos2d", "cov2d", "radius_full",
                  "bbox", "ntiles", "rec", "order", "slot_base", "slot_seq", "tile_offsets", "tile_order", "pair_slot", "sorted_gauss",
-                 "stream_rec", "final_T", "img", "pairgrad", "_counters", "_host", "_ready", "_slot_rest")
+                 "stream_rec", "final_T", "img", "pairgrad", "blocks", "_counters", "_host", "_ready", "_slot_rest")
 
     def __init__(self):
         for s in self.__slots__:
@@ -344,6 +344,52 @@ def _lists_of(st: RenderState) -> RenderState:
     if os.environ.get("GSR_TILE_ORDER", "length") != "id":      # "id": tile-id order (for comparisons)
         st.tile_order = torch.empty(T, **i32)
         _call("gsr_tile_order", lib.gsr_tile_order, cv, _ptr(st.tile_offsets), _ptr(st.tile_order), stream)
+    return _block_lists_of(st)
+
+
+class BlockLists:
+    """The per-block streams of a view whose tiles are 2x2, 3x3 or 4x4 blocks (``gsr_block_lists``): what the compositing
+    kernels of one-block tiles walk instead of the tile lists."""
+    __slots__ = ("offsets", "order", "stream", "combo", "cview16")
+
+    def __init__(self, offsets, order, stream, combo, cview16):
+        self.offsets, self.order, self.stream, self.combo, self.cview16 = offsets, order, stream, combo, cview16
+
+
+def block_lists_enabled() -> bool:
+    """``GSR_BLOCK_LISTS=0`` keeps tiles of several blocks on the tile-group kernels (read at every call: tests compare
+    the two paths inside one process)."""
+    return os.environ.get("GSR_BLOCK_LISTS", "1") != "0"
+
+
+def _block_lists_of(st: RenderState) -> RenderState:
+    """Builds ``st.blocks`` when the view qualifies (tile edge 32, 48 or 64, few enough pairs); else leaves it None."""
+    st.blocks = None
+    if not st.num_visible or not st.num_pairs or not block_lists_enabled():
+        return st
+    lib = _lib.load()
+    cv, I = st.cview, st.num_pairs
+    if not lib.gsr_block_lists_supported(cv, I):
+        return st
+    dev = st.mask_u8.device
+    stream = _stream(dev)
+    S2 = (st.view.tile_length // 16) ** 2
+    T16 = int(lib.gsr_block_count(cv))
+    i32 = dict(dtype=torch.int32, device=dev)
+    offsets = torch.empty(T16 + 1, **i32)
+    block_stream = torch.empty(I * S2, _lib.STREAM_DWORDS, dtype=torch.float32, device=dev)   # (the upper bound)
+    combo = torch.empty(I * S2, **i32)
+    ws_bytes = int(lib.gsr_block_lists_workspace_bytes(cv, I))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _call("gsr_block_lists", lib.gsr_block_lists, cv, _ptr(st.tile_offsets), _ptr(st.stream_rec), I, _ptr(offsets), _ptr(block_stream),
+          _ptr(combo), _ptr(ws), ws_bytes, stream)
+    cv16 = _lib.GsrView.from_buffer_copy(cv)
+    cv16.tile_length = 16
+    order = None
+    if os.environ.get("GSR_TILE_ORDER", "length") != "id":
+        order = torch.empty(T16, **i32)
+        _call("gsr_tile_order", lib.gsr_tile_order, cv16, _ptr(offsets), _ptr(order), stream)
+    st.blocks = BlockLists(offsets, order, block_stream, combo, cv16)
     return st
 
 
@@ -423,6 +469,7 @@ def forward_lists_views(states) -> list:
         b, I = int(bases[k]), max(st.num_pairs, 1)
         st.tile_offsets, st.tile_order = tile_offsets[k], tile_order[k]
         st.sorted_gauss, st.stream_rec = sorted_gauss[b:b + I], stream_rec[b:b + I]
+        _block_lists_of(st)
     return states
 
 
@@ -436,6 +483,11 @@ def forward_composite(st: RenderState) -> RenderState:
     f32 = dict(dtype=torch.float32, device=dev)
     st.img = torch.empty(view.width, view.height, 3, **f32)
     st.final_T = torch.empty(view.width, view.height, **f32)
+    if st.blocks is not None:
+        b = st.blocks
+        _call("gsr_composite_blocks_fwd", lib.gsr_composite_blocks_fwd, st.cview, st.num_pairs, _ptr(b.offsets), _ptr(b.order),
+              _ptr(b.stream), _ptr(st.img), _ptr(st.final_T), _stream(dev))
+        return st
     _call("gsr_composite_fwd", lib.gsr_composite_fwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec),
           _ptr(st.img), _ptr(st.final_T), _stream(dev))
     return st
@@ -454,8 +506,34 @@ def forward_pipeline(coords, scale_raw, rot_raw, opac_raw, sh, screen_coords, vi
 
 def _alloc_pairgrad(lib, st: RenderState, dev) -> torch.Tensor:
     """The gradient records of a view: one row per (tile, Gaussian) pair and per workgroup of the pair's tile."""
-    rows = max(st.num_pairs, 1) * int(lib.gsr_pairgrad_parts(st.view.tile_length))
+    rows = max(st.num_pairs, 1) * pairgrad_parts(st)
     return torch.empty(rows, _lib.PAIRGRAD_FLOATS, dtype=torch.float32, device=dev)
+
+
+def pairgrad_parts(st: RenderState) -> int:
+    """Rows of ``pairgrad`` per pair as ``_composite_bwd`` leaves them (1 with per-block lists: their rows are summed per
+    pair before the per-Gaussian sums)."""
+    return 1 if st.blocks is not None else int(_lib.load().gsr_pairgrad_parts(st.view.tile_length))
+
+
+def _composite_bwd(lib, st: RenderState, dimg, dev) -> torch.Tensor:
+    """Compositing backward on the current stream; returns the gradient records at the pairs' emission slots."""
+    stream = _stream(dev)
+    pairgrad = _alloc_pairgrad(lib, st, dev)
+    if st.blocks is None:
+        _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec),
+              _ptr(st.final_T), _ptr(dimg), st.num_pairs, _ptr(pairgrad), stream)
+        return pairgrad
+    b, I = st.blocks, st.num_pairs
+    S2 = (st.view.tile_length // 16) ** 2
+    f32 = dict(dtype=torch.float32, device=dev)
+    rows = torch.empty(max(I, 1) * S2, _lib.PAIRGRAD_FLOATS, **f32)     # written where a block evaluates an entry
+    run_sums = torch.empty(max(I, 1) * S2, 8, **f32)                    # one row per run record (upper bound)
+    _call("gsr_composite_blocks_bwd", lib.gsr_composite_blocks_bwd, st.cview, I, _ptr(b.offsets), _ptr(b.order), _ptr(b.stream),
+          _ptr(st.final_T), _ptr(dimg), _ptr(rows), _ptr(run_sums), stream)
+    _call("gsr_block_rows_reduce", lib.gsr_block_rows_reduce, st.cview, I, _ptr(st.stream_rec), _ptr(b.combo), _ptr(rows),
+          _ptr(run_sums), _ptr(pairgrad), stream)
+    return pairgrad
 
 
 def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh, dimg, accumulate_into=None,
@@ -473,10 +551,18 @@ def backward_pipeline(st: RenderState, coords, scale_raw, rot_raw, opac_raw, sh,
     I = st.num_pairs
     if st._slot_rest is not None:
         forward_slot_bases([st])
-    pairgrad = _alloc_pairgrad(lib, st, dev)
-    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec), _ptr(st.final_T),
-                                     _ptr(dimg), I, _ptr(pairgrad), stream)
+    pairgrad = _composite_bwd(lib, st, dimg, dev)
     st.pairgrad = pairgrad
+    if st.blocks is not None:
+        # (one row per pair: the one-view convenience call below would read gsr_pairgrad_parts(tile edge) rows)
+        gsum = record_sums(st, pairgrad)
+        five = None if accumulate_into is None else tuple(accumulate_into[:5])
+        grads5, g_screens = backward_views([st], [gsum], coords, scale_raw, rot_raw, opac_raw, sh, grads=five,
+                                           accumulate=accumulate_into is not None and not overwrite)
+        if accumulate_into is None:
+            return tuple(grads5) + (g_screens[0],)
+        accumulate_into[5].copy_(g_screens[0])
+        return accumulate_into
     if accumulate_into is None:
         grads = (torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32),
                  torch.empty(n, 1, **f32), torch.empty(n, 3, 16, **f32), torch.empty(n, 3, **f32))
@@ -500,10 +586,7 @@ def backward_composite(st: RenderState, dimg) -> torch.Tensor:
     lib = _lib.load()
     dev = st.mask_u8.device
     dimg = dimg.to(torch.float32).contiguous()
-    pairgrad = _alloc_pairgrad(lib, st, dev)
-    _call("gsr_composite_bwd", lib.gsr_composite_bwd, st.cview, _ptr(st.tile_offsets), _ptr(st.tile_order), _ptr(st.stream_rec),
-          _ptr(st.final_T), _ptr(dimg), st.num_pairs, _ptr(pairgrad), _stream(dev))
-    return pairgrad
+    return _composite_bwd(lib, st, dimg, dev)
 
 
 def record_sums(st: RenderState, pairgrad: torch.Tensor, gsum: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -514,7 +597,7 @@ def record_sums(st: RenderState, pairgrad: torch.Tensor, gsum: Optional[torch.Te
     dev = st.mask_u8.device
     if gsum is None:
         gsum = torch.empty(st.n, 12, dtype=torch.float32, device=dev)
-    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, int(lib.gsr_pairgrad_parts(st.view.tile_length)), _ptr(st.mask_u8),
+    _call("gsr_pair_reduce", lib.gsr_pair_reduce, st.n, pairgrad_parts(st), _ptr(st.mask_u8),
           _ptr(st.slot_base), _ptr(st.ntiles), _ptr(pairgrad), _ptr(gsum), _stream(dev))
     return gsum
 

@@ -241,7 +241,9 @@ def main():
     # Timed region: only the dominant kernel's entry point is bracketed by HIP events (on the stream it
     # is launched on); timing every call costs about 2.5 % of the step.
     dom = "composite_fwd" if args.forward_only else "composite_bwd"
-    with StageTimer(only=("gsr_" + dom,)) as timer:
+    # (tile edges 32, 48 and 64 composite per-block streams: entry points gsr_composite_blocks_*)
+    dom_names = ("gsr_" + dom, "gsr_" + dom.replace("composite_", "composite_blocks_"))
+    with StageTimer(only=dom_names) as timer:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -278,8 +280,12 @@ def main():
         # once per step for all views of the rank; pair_reduce + preprocess_bwd_views = stage-1 backward)
         views_timed = max(len(views), 1) * breakdown_steps
         stage_ms = {k.replace("gsr_", ""): v[1] / views_timed for k, v in stage.items()}
+        for d in ("fwd", "bwd"):     # one name for the compositing stage, whichever entry point ran
+            if "composite_blocks_" + d in stage_ms:
+                stage_ms["composite_" + d] = stage_ms.get("composite_" + d, 0.0) + stage_ms.pop("composite_blocks_" + d)
         stage_ms["preprocess_bwd"] = stage_ms.get("pair_reduce", 0.0) + stage_ms.get("preprocess_bwd_views", 0.0)
-        calls, total_ms = dominant.get("gsr_" + dom, (0, float("nan")))
+        calls = sum(dominant.get(k, (0, 0.0))[0] for k in dom_names)
+        total_ms = sum(dominant.get(k, (0, 0.0))[1] for k in dom_names) if calls else float("nan")
         dom_ms = total_ms / max(calls, 1)      # average launch duration over the timed region
         dom_alone_ms = stage_ms.get(dom)
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9

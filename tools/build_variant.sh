@@ -12,7 +12,7 @@ csrc=$root/3d-gaussian-splatting_amd/csrc
 mkdir -p "$root/var/$name"
 make -C "$csrc" -j8 > /dev/null
 objs=""
-for src in api preprocess scan_sort binning composite loss adam densify knn; do
+for src in api preprocess scan_sort binning blocklists composite loss adam densify knn; do
   if echo " $files " | grep -q " $src.hip "; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize \
       -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-sanitize -Wall -Wno-unused-function $flags \
