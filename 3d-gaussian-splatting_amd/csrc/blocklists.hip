@@ -147,15 +147,21 @@ __global__ __launch_bounds__(256) void block_count_kernel(ViewK v, const uint32_
     if (owner) counts[own_at] = own_count;
 }
 
-// 0.99^n and sum_i 0.99^i 0.01 c_i over the entries of the run up to this lane.  The power is kept in double and
-// rounded once: a product of rounded float factors has the same error for every run of the same length, and over the
-// few hundred runs of a list that adds up (2e-5 of the transmittance at a tile edge of 64) instead of averaging out
-// as the roundings of the entry-by-entry product do.
-struct RunSums {
-    double P;
-    float r, g, b;
+// 0.99^n for n = 0 .. 64, each the exact power of the float 0.99 rounded ONCE (formed in double at compile time).  A
+// product of rounded float factors would have the same error for every run of the same length, and over the few hundred
+// runs of a list that adds up (2e-5 of the transmittance at a tile edge of 64) instead of averaging out as the roundings
+// of the entry-by-entry product do.
+struct Pow99 {
+    float v[kChunk + 1];
+    constexpr Pow99() : v()
+    {
+        double p = 1.0;
+        for (uint32_t i = 0; i <= kChunk; ++i) { v[i] = (float)p; p *= (double)(1.0f - kAlphaFloor); }
+    }
 };
+__constant__ Pow99 kPow99 = Pow99();
 
+template <int S>
 __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                           const float *__restrict__ stream_rec,
                                                           const uint32_t *__restrict__ chunk_base_tile,
@@ -163,6 +169,10 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
                                                           const uint32_t *__restrict__ first_record,   // scanned counts
                                                           float *__restrict__ block_stream, uint32_t *__restrict__ combo)
 {
+    constexpr int S2 = S * S;
+    __shared__ float pow99[kChunk + 1];
+    if (threadIdx.x <= kChunk) pow99[threadIdx.x] = kPow99.v[threadIdx.x];
+    __syncthreads();
     uint32_t t, k;
     if (!wave_chunk(v, chunk_base_tile, t, k)) return;
     const BlockGrid g = block_grid(v);
@@ -178,16 +188,15 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
     const float red = q1.z, green = q2.x, blue = q2.z;
     const unsigned long long below = (1ull << lane) - 1ull;
     // lane c fetches where block c's records of this chunk start (one dependent load per wave, not one per block)
-    const BlockOfTile own = block_of_tile(v, g, t, min(lane, g.S2 - 1));
-    const uint32_t own_first = (lane < g.S2 && own.inside) ? first_record[chunk_base_block[own.id] + k] : 0u;
-    for (int c = 0; c < g.S2; ++c) {
+    const BlockOfTile own = block_of_tile(v, g, t, min(lane, S2 - 1));
+    const uint32_t own_first = (lane < S2 && own.inside) ? first_record[chunk_base_block[own.id] + k] : 0u;
+    uint32_t cmb[S2];   // the entry's word of every block: stored together after the loop (S2 consecutive words per entry)
+#pragma unroll
+    for (int c = 0; c < S2; ++c) {
         const BlockOfTile b = block_of_tile(v, g, t, c);
-        const size_t at = (size_t)p * (size_t)g.S2 + (size_t)c;
         const uint32_t first = (uint32_t)__shfl((int)own_first, c, 64);
-        if (!b.inside) {
-            if (valid) combo[at] = kOutside;
-            continue;
-        }
+        cmb[c] = kOutside;
+        if (!b.inside) continue;
         const uint32_t f = (flags >> (2 * c)) & 3u;
         const bool clamped = valid && f == 3u;
         const unsigned long long cm = __ballot(clamped);
@@ -197,40 +206,46 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
         const unsigned long long heads = cm & ~(cm << 1);
         const unsigned long long mine = heads & (below | (1ull << lane));
         const int idx = clamped ? lane - (63 - __clzll((long long)mine)) : 0;
-        // inclusive scan inside the run of the maps (T, C) -> (0.99 T, C + T 0.01 c): (P1, C1) then (P2, C2) is
-        // (P1 P2, C1 + P1 C2)
-        RunSums s = {(double)(1.0f - kAlphaFloor), kAlphaFloor * red, kAlphaFloor * green, kAlphaFloor * blue};
+        // the run's colour sum_i 0.99^i 0.01 c_i: every entry weighted by the power of its index, then an inclusive
+        // sum inside the run
+        const float wi = pow99[idx] * kAlphaFloor;
+        float sr = wi * red, sg = wi * green, sb = wi * blue;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const double P1 = __shfl_up(s.P, d, 64);
-            const float r1 = __shfl_up(s.r, d, 64), g1 = __shfl_up(s.g, d, 64), b1 = __shfl_up(s.b, d, 64);
-            if (idx >= d) {
-                const float P1f = (float)P1;
-                s.r = fmaf(P1f, s.r, r1); s.g = fmaf(P1f, s.g, g1); s.b = fmaf(P1f, s.b, b1);
-                s.P = P1 * s.P;
-            }
+            const float r1 = __shfl_up(sr, d, 64), g1 = __shfl_up(sg, d, 64), b1 = __shfl_up(sb, d, 64);
+            if (idx >= d) { sr += r1; sg += g1; sb += b1; }
         }
         if (!valid) continue;
         float4 *dst = reinterpret_cast<float4 *>(block_stream + (size_t)rid * GSR_STREAM_DWORDS);
         if (!clamped) {
             // the entry's own record in the layout of a one-block tile: ... | g row+flags b b/100 | cbh r/100 cd g/100
-            const uint32_t row = (uint32_t)at;
+            const uint32_t row = p * (uint32_t)S2 + (uint32_t)c;
             dst[0] = q0; dst[1] = q1;
             dst[2] = make_float4(green, __uint_as_float(row | (f << 30)), blue, kAlphaFloor * blue);
             dst[3] = make_float4(q3.x, kAlphaFloor * red, q3.z, kAlphaFloor * green);
-            combo[at] = kEvaluated;
+            cmb[c] = kEvaluated;
         } else {
-            combo[at] = (rid << 6) | (uint32_t)idx;
+            cmb[c] = (rid << 6) | (uint32_t)idx;
             const bool last = lane == 63 || !((cm >> (lane + 1)) & 1ull);
             if (last) {
                 // a run: dword 4 = 0.99^n, dword 5 = its reciprocal, dword 9 = the record's own index (its row of the run
                 // sums) with both hint bits set, dwords 11, 13, 15 = the run's colour (blue, red, green)
+                const float P = pow99[idx + 1];
                 dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float P = (float)s.P;
                 dst[1] = make_float4(P, 1.0f / P, 0.f, 0.f);
-                dst[2] = make_float4(0.f, __uint_as_float(rid | (3u << 30)), 0.f, s.b);
-                dst[3] = make_float4(0.f, s.r, 0.f, s.g);
+                dst[2] = make_float4(0.f, __uint_as_float(rid | (3u << 30)), 0.f, sb);
+                dst[3] = make_float4(0.f, sr, 0.f, sg);
             }
+        }
+    }
+    if (valid) {
+        uint32_t *dst = combo + (size_t)p * (size_t)S2;
+        if (S2 % 4 == 0) {
+#pragma unroll
+            for (int c = 0; c < S2; c += 4) reinterpret_cast<uint4 *>(dst)[c / 4] = make_uint4(cmb[c], cmb[c + 1], cmb[c + 2], cmb[c + 3]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < S2; ++c) dst[c] = cmb[c];
         }
     }
 }
@@ -370,8 +385,16 @@ extern "C" int gsr_block_lists(const gsr_view *view_host, const uint32_t *tile_o
     hipLaunchKernelGGL(block_count_kernel, dim3(gsr_div_up(waves, 4)), dim3(256), 0, s, v, tile_offsets, stream_rec, chunk_base_tile,
                        chunk_base_block, counts);
     if (int e = gsr_exclusive_scan(counts, counts, l.n_counts, total, ws + l.off_scan, l.scan_bytes, stream)) return e;
-    hipLaunchKernelGGL(block_write_kernel, dim3(gsr_div_up(waves, 4)), dim3(256), 0, s, v, tile_offsets, stream_rec, chunk_base_tile,
-                       chunk_base_block, counts, block_stream, combo);
+    const dim3 grid(gsr_div_up(waves, 4)), block(256);
+    if (g.S == 2)
+        hipLaunchKernelGGL(block_write_kernel<2>, grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
+                           block_stream, combo);
+    else if (g.S == 3)
+        hipLaunchKernelGGL(block_write_kernel<3>, grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
+                           block_stream, combo);
+    else
+        hipLaunchKernelGGL(block_write_kernel<4>, grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
+                           block_stream, combo);
     hipLaunchKernelGGL(block_offsets_kernel, dim3(gsr_div_up((unsigned)g.T16 + 1u, 256)), dim3(256), 0, s, (uint32_t)g.T16,
                        chunk_base_block, counts, total, block_offsets);
     return gsr_check_launch("block_lists");

@@ -341,10 +341,12 @@ def _lists_of(st: RenderState) -> RenderState:
                                  _ptr(st.tile_offsets), None, _ptr(st.sorted_gauss),
                                  _ptr(st.stream_rec), _ptr(ws), ws_bytes, stream)
     st.tile_order = None
+    if _block_lists_of(st).blocks is not None:
+        return st                                                # (the compositing kernels take the blocks' order)
     if os.environ.get("GSR_TILE_ORDER", "length") != "id":      # "id": tile-id order (for comparisons)
         st.tile_order = torch.empty(T, **i32)
         _call("gsr_tile_order", lib.gsr_tile_order, cv, _ptr(st.tile_offsets), _ptr(st.tile_order), stream)
-    return _block_lists_of(st)
+    return st
 
 
 class BlockLists:
@@ -356,16 +358,19 @@ class BlockLists:
         self.offsets, self.order, self.stream, self.combo, self.cview16 = offsets, order, stream, combo, cview16
 
 
-def block_lists_enabled() -> bool:
-    """``GSR_BLOCK_LISTS=0`` keeps tiles of several blocks on the tile-group kernels (read at every call: tests compare
-    the two paths inside one process)."""
-    return os.environ.get("GSR_BLOCK_LISTS", "1") != "0"
+def block_lists_enabled(tile_length: int) -> bool:
+    """Whether a view of this tile edge is composited from per-block lists when the library supports it.  By default
+    the edges 48 and 64, where it is 1.5 to 1.8 times as fast as the tile-group kernels; at 32 the two are level (628
+    against 622 renders/s at 1 M Gaussians, 1080p) and the tile groups need less memory.  ``GSR_BLOCK_LISTS=0``: never;
+    ``GSR_BLOCK_LISTS=all``: every supported edge (read at every call: tests compare the paths inside one process)."""
+    mode = os.environ.get("GSR_BLOCK_LISTS", "1")
+    return mode != "0" and (tile_length >= 48 or mode == "all")
 
 
 def _block_lists_of(st: RenderState) -> RenderState:
     """Builds ``st.blocks`` when the view qualifies (tile edge 32, 48 or 64, few enough pairs); else leaves it None."""
     st.blocks = None
-    if not st.num_visible or not st.num_pairs or not block_lists_enabled():
+    if not st.num_visible or not st.num_pairs or not block_lists_enabled(st.view.tile_length):
         return st
     lib = _lib.load()
     cv, I = st.cview, st.num_pairs

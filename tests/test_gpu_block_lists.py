@@ -33,7 +33,7 @@ def _restore_switch():
 
 def _render(p, view, cot, blocks):
     from gsplat_amd import rasterizer as R
-    os.environ["GSR_BLOCK_LISTS"] = "1" if blocks else "0"
+    os.environ["GSR_BLOCK_LISTS"] = "all" if blocks else "0"
     st = R.forward_pipeline(*p, None, view)
     grads = R.backward_pipeline(st, *p, cot)
     torch.cuda.synchronize()
@@ -83,7 +83,7 @@ def test_block_streams_follow_the_hint_flags(tile, W, H):
     dev = torch.device("cuda:0")
     sc = _scene("adv", 20000, W, H, 1, 9)
     p = [t.to(dev) for t in sc.params()]
-    os.environ["GSR_BLOCK_LISTS"] = "1"
+    os.environ["GSR_BLOCK_LISTS"] = "all"
     st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, tile))
     torch.cuda.synchronize()
     assert st.blocks is not None
@@ -164,11 +164,13 @@ def test_views_that_keep_the_tile_groups():
     p = [t.to(dev) for t in sc.params()]
     lib = _lib.load()
     for tile, want in ((16, False), (40, False), (80, False), (32, True), (48, True), (64, True)):
-        os.environ["GSR_BLOCK_LISTS"] = "1"
-        st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, tile))
-        assert (st.blocks is not None) == want
-        assert bool(lib.gsr_block_lists_supported(st.cview, st.num_pairs)) == want
-        assert R.pairgrad_parts(st) == (1 if want else int(lib.gsr_pairgrad_parts(tile)))
+        for mode in ("1", "all"):
+            os.environ["GSR_BLOCK_LISTS"] = mode
+            st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, tile))
+            used = want and (mode == "all" or tile >= 48)        # (by default only where it is faster: edges 48 and 64)
+            assert (st.blocks is not None) == used
+            assert bool(lib.gsr_block_lists_supported(st.cview, st.num_pairs)) == want
+            assert R.pairgrad_parts(st) == (1 if used else int(lib.gsr_pairgrad_parts(tile)))
     os.environ["GSR_BLOCK_LISTS"] = "0"
     st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, 64))
     assert st.blocks is None
