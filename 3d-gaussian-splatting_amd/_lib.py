@@ -134,8 +134,8 @@ def load():
     lib.gsr_block_lists_workspace_bytes.argtypes = [C.POINTER(GsrView), C.c_uint32]
     lib.gsr_block_lists.argtypes = [C.POINTER(GsrView), vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_size_t, vp]
     lib.gsr_composite_blocks_fwd.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, vp, vp, vp, vp]
-    lib.gsr_composite_blocks_bwd.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.gsr_block_rows_reduce.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, vp, vp, vp, vp]
+    lib.gsr_composite_blocks_bwd.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_block_rows_reduce.argtypes = [C.POINTER(GsrView), C.c_uint32, vp, vp, vp, vp, vp]
     lib.gsr_composite_bwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, C.c_uint32, vp, vp]
     lib.gsr_loss_workspace_bytes.restype = C.c_size_t
     lib.gsr_loss_workspace_bytes.argtypes = [C.c_int, C.c_int]

@@ -11,22 +11,23 @@
 // entries that are clamped on the whole block becomes ONE record that carries the two constants.  The compositing
 // kernels of one-block tiles then walk these streams (composite.hip, `RUNS`), a fifth of the records.
 //
-// Runs end at multiples of 64 list positions (a wave handles 64 consecutive entries of a tile on its own), so the
-// kernels below need no carries between waves.
+// Runs end at multiples of 32 list positions of their tile (a wave handles 64 consecutive entries of a tile on its own,
+// and the index of an entry inside its run fits five bits), so the kernels below need no carries between waves.
 //
 // Outputs, for a view of T16 = ceil(W/16) * ceil(H/16) blocks (block id = Y16 + ceil(H/16) * X16, the tile id of the
 // same view at a tile edge of 16):
 //   block_offsets[T16 + 1]  range of each block's records in block_stream
-//   block_stream[R, 16]     the records; a full record names its gradient row p * S^2 + c (p: position of the entry in
-//                           the tile lists, c: block inside the tile), a run record its own index
-//   combo[I * S^2]          per list position p and block c: 0xFFFFFFFF = the block evaluates the entry (a gradient row
-//                           exists), 0xFFFFFFFE = the block lies outside the image, else run << 6 | index inside the run
+//   block_stream[R, 16]     the records; every record carries its own index r, which is also the row the compositing
+//                           backward writes for it: a wave's stores follow its walk through the stream
+//   combo[I * S^2]          per list position p and block c: 0xFFFFFFFF = the block lies outside the image, else
+//                           r << 6 | 32 = the block evaluates the entry (record r), or r << 6 | index inside run r
 #include "gsr_common.hpp"
 
 namespace {
 
 constexpr uint32_t kChunk = 64;
-constexpr uint32_t kEvaluated = 0xFFFFFFFFu, kOutside = 0xFFFFFFFEu;
+constexpr uint32_t kOutside = 0xFFFFFFFFu, kEvaluatedBit = 32u, kRunIndexMask = 31u;
+constexpr unsigned long long kRunBreaks = (1ull << 32) | 1ull;   // lanes at which a run always starts anew
 constexpr float kAlphaFloor = 0.01f;
 
 struct BlockGrid {
@@ -114,11 +115,13 @@ __device__ inline BlockOfTile block_of_tile(const ViewK &v, const BlockGrid &g, 
 }
 
 // lanes that leave a record in the block's stream: every evaluated entry, and the last entry of every run
-__device__ inline unsigned long long emitters(bool valid, bool clamped, int lane)
+// `joined`: the clamped lanes that continue the run of the lane below them
+__device__ inline unsigned long long emitters(bool valid, bool clamped, int lane, unsigned long long &cm, unsigned long long &joined)
 {
-    const unsigned long long cm = __ballot(clamped);
-    const bool next_clamped = lane < 63 && ((cm >> (lane + 1)) & 1ull);
-    return __ballot(valid && (!clamped || !next_clamped));
+    cm = __ballot(clamped);
+    joined = cm & (cm << 1) & ~kRunBreaks;
+    const bool next_joined = lane < 63 && ((joined >> (lane + 1)) & 1ull);
+    return __ballot(valid && (!clamped || !next_joined));
 }
 
 __global__ __launch_bounds__(256) void block_count_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(256) void block_count_kernel(ViewK v, const uint32_
     uint32_t own_count = 0;
     for (int c = 0; c < g.S2; ++c) {
         const bool clamped = valid && ((flags >> (2 * c)) & 3u) == 3u;
-        const unsigned long long em = emitters(valid, clamped, lane);
+        unsigned long long cm, joined;
+        const unsigned long long em = emitters(valid, clamped, lane, cm, joined);
         if (lane == c) own_count = (uint32_t)__popcll(em);
     }
     if (owner) counts[own_at] = own_count;
@@ -199,11 +203,11 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
         if (!b.inside) continue;
         const uint32_t f = (flags >> (2 * c)) & 3u;
         const bool clamped = valid && f == 3u;
-        const unsigned long long cm = __ballot(clamped);
-        const unsigned long long em = emitters(valid, clamped, lane);
+        unsigned long long cm, joined;
+        const unsigned long long em = emitters(valid, clamped, lane, cm, joined);
         const uint32_t rid = first + (uint32_t)__popcll(em & below);
         // index of the lane inside its run: distance to the nearest lane at or below it that starts a run
-        const unsigned long long heads = cm & ~(cm << 1);
+        const unsigned long long heads = cm & ~joined;
         const unsigned long long mine = heads & (below | (1ull << lane));
         const int idx = clamped ? lane - (63 - __clzll((long long)mine)) : 0;
         // the run's colour sum_i 0.99^i 0.01 c_i: every entry weighted by the power of its index, then an inclusive
@@ -211,25 +215,24 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
         const float wi = pow99[idx] * kAlphaFloor;
         float sr = wi * red, sg = wi * green, sb = wi * blue;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
+        for (int d = 1; d < 32; d <<= 1) {
             const float r1 = __shfl_up(sr, d, 64), g1 = __shfl_up(sg, d, 64), b1 = __shfl_up(sb, d, 64);
             if (idx >= d) { sr += r1; sg += g1; sb += b1; }
         }
         if (!valid) continue;
         float4 *dst = reinterpret_cast<float4 *>(block_stream + (size_t)rid * GSR_STREAM_DWORDS);
         if (!clamped) {
-            // the entry's own record in the layout of a one-block tile: ... | g row+flags b b/100 | cbh r/100 cd g/100
-            const uint32_t row = p * (uint32_t)S2 + (uint32_t)c;
+            // the entry's own record in the layout of a one-block tile: ... | g index+flags b b/100 | cbh r/100 cd g/100
             dst[0] = q0; dst[1] = q1;
-            dst[2] = make_float4(green, __uint_as_float(row | (f << 30)), blue, kAlphaFloor * blue);
+            dst[2] = make_float4(green, __uint_as_float(rid | (f << 30)), blue, kAlphaFloor * blue);
             dst[3] = make_float4(q3.x, kAlphaFloor * red, q3.z, kAlphaFloor * green);
-            cmb[c] = kEvaluated;
+            cmb[c] = (rid << 6) | kEvaluatedBit;
         } else {
             cmb[c] = (rid << 6) | (uint32_t)idx;
-            const bool last = lane == 63 || !((cm >> (lane + 1)) & 1ull);
+            const bool last = lane == 63 || !((joined >> (lane + 1)) & 1ull);
             if (last) {
-                // a run: dword 4 = 0.99^n, dword 5 = its reciprocal, dword 9 = the record's own index (its row of the run
-                // sums) with both hint bits set, dwords 11, 13, 15 = the run's colour (blue, red, green)
+                // a run: dword 4 = 0.99^n, dword 5 = its reciprocal, dword 9 = the record's own index with both hint bits
+                // set, dwords 11, 13, 15 = the run's colour (blue, red, green)
                 const float P = pow99[idx + 1];
                 dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                 dst[1] = make_float4(P, 1.0f / P, 0.f, 0.f);
@@ -260,51 +263,74 @@ __global__ __launch_bounds__(256) void block_offsets_kernel(uint32_t T16, const 
     block_offsets[b] = i < chunk_base_block[T16] ? first_record[i] : *total;
 }
 
-// One gradient record per pair from what the blocks of its tile left: the rows of the blocks that evaluated the entry
-// (rows[p S^2 + c], written by the compositing backward), and for the blocks on which the entry was part of a run the
-// colour gradient 0.01 * 0.99^i * U, U = the run's sum over the block's pixels of (transmittance in front of the run) x
-// (cotangent), which the backward stored in run_sums[run] (red, green, four partial sums of blue).
-// Sixteen lanes per pair, one per block; their values meet in a fixed butterfly, so the result is reproducible.
-__global__ __launch_bounds__(256) void block_rows_reduce_kernel(int S2, uint32_t num_pairs, const float *__restrict__ stream_rec,
+// One gradient record per pair from what the blocks of its tile left in block_grad (one row per record of the block
+// streams, written by the compositing backward): the rows of the records with which blocks evaluated the entry, and for
+// the blocks on which the entry was part of a run the colour gradient 0.01 * 0.99^i * U, U = the run's sum over the
+// block's pixels of (transmittance in front of the run) x (cotangent), the first six floats of the run's row (red,
+// green, four partial sums of blue).
+// A workgroup takes 64 consecutive list positions; a wave walks them for one block at a time (wave w: blocks w, w + 4,
+// ...), so that neighbouring lanes - neighbouring entries of a list, which mostly sit in the same run - read the same
+// run sums.  The combination words arrive through LDS (loaded as they lie, read by block), the four waves' partial
+// sums meet in LDS and are added in wave order: fixed orders throughout, the result is reproducible.
+template <int S2>
+__global__ __launch_bounds__(256) void block_rows_reduce_kernel(uint32_t num_pairs, const float *__restrict__ stream_rec,
                                                                 const uint32_t *__restrict__ combo,
-                                                                const float *__restrict__ rows, const float *__restrict__ run_sums,
-                                                                float *__restrict__ pairgrad)
+                                                                const float *__restrict__ block_grad, float *__restrict__ pairgrad)
 {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t p = tid >> 4;
-    const int c = (int)(tid & 15u);
-    const bool pair = p < num_pairs;
+    __shared__ uint32_t words[S2 * 65];        // [block][entry], rows padded to 65
+    __shared__ float part[4 * 9 * 64];         // [wave][sum][entry]
+    const uint32_t p0 = blockIdx.x * 64u;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const uint32_t count = min(64u, num_pairs - p0);
+    for (uint32_t i = threadIdx.x; i < count * (uint32_t)S2; i += 256u) {
+        const uint32_t e = i / (uint32_t)S2, c = i - e * (uint32_t)S2;
+        words[c * 65u + e] = combo[(size_t)p0 * S2 + i];
+    }
+    __syncthreads();
     float val[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) val[j] = 0.0f;
-    if (pair && c < S2) {
-        const size_t at = (size_t)p * (size_t)S2 + (size_t)c;
-        const uint32_t m = combo[at];
-        if (m == kEvaluated) {
-            const float4 *src = reinterpret_cast<const float4 *>(rows + at * GSR_PAIRGRAD_FLOATS);
-            const float4 a = src[0], b = src[1], d = src[2];
-            val[0] = a.x; val[1] = a.y; val[2] = a.z; val[3] = a.w;
-            val[4] = b.x; val[5] = b.y; val[6] = b.z; val[7] = b.w;
-            val[8] = (d.x + d.y) + (d.z + d.w);
-        } else if (m != kOutside) {
-            const float4 *src = reinterpret_cast<const float4 *>(run_sums + (size_t)(m >> 6) * 8);
-            const float4 a = src[0], b = src[1];                       // r g b0 b1 | b2 b3 - -
-            const float wgt = kAlphaFloor * __builtin_amdgcn_exp2f((float)(m & 63u) * -0.014499569695115089f);   // 0.01 * 0.99^i
-            val[6] = wgt * a.x;
-            val[7] = wgt * a.y;
-            val[8] = wgt * ((a.z + a.w) + (b.x + b.y));
+    if ((uint32_t)l < count) {
+        // (all loads of the wave's blocks are issued before the first sum)
+        constexpr int kTurns = (S2 + 3) / 4;
+        uint32_t m[kTurns];
+        float4 a[kTurns], b[kTurns], d[kTurns];
+#pragma unroll
+        for (int q = 0; q < kTurns; ++q) {
+            const int c = w + 4 * q;
+            m[q] = c < S2 ? words[c * 65 + l] : kOutside;
+            a[q] = b[q] = d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m[q] == kOutside) continue;
+            const float4 *src = reinterpret_cast<const float4 *>(block_grad + (size_t)(m[q] >> 6) * GSR_PAIRGRAD_FLOATS);
+            a[q] = src[0]; b[q] = src[1];                                 // (a run: r g b0 b1 | b2 b3 - -)
+            if (m[q] & kEvaluatedBit) d[q] = src[2];
+        }
+#pragma unroll
+        for (int q = 0; q < kTurns; ++q) {
+            if (m[q] == kOutside) continue;
+            if (m[q] & kEvaluatedBit) {
+                val[0] += a[q].x; val[1] += a[q].y; val[2] += a[q].z; val[3] += a[q].w;
+                val[4] += b[q].x; val[5] += b[q].y; val[6] += b[q].z; val[7] += b[q].w;
+                val[8] += (d[q].x + d[q].y) + (d[q].z + d[q].w);
+            } else {
+                const float wgt = kAlphaFloor * __builtin_amdgcn_exp2f((float)(m[q] & kRunIndexMask) * -0.014499569695115089f);   // 0.01 * 0.99^i
+                val[6] = fmaf(wgt, a[q].x, val[6]);
+                val[7] = fmaf(wgt, a[q].y, val[7]);
+                val[8] = fmaf(wgt, (a[q].z + a[q].w) + (b[q].x + b[q].y), val[8]);
+            }
         }
     }
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) val[j] += __shfl_xor(val[j], d, 16);
-    }
-    if (pair && c < 3) {
-        const uint32_t slot = __float_as_uint(stream_rec[(size_t)p * GSR_STREAM_DWORDS + 9]);
+    for (int j = 0; j < 9; ++j) part[(w * 9 + j) * 64 + l] = val[j];
+    __syncthreads();
+    // 64 entries x 3 float4 of output: thread t writes float4 (t % 3) of entry t / 3 (the first 192 threads)
+    const uint32_t e = threadIdx.x / 3u, q = threadIdx.x - e * 3u;
+    if (threadIdx.x < 192u && e < count) {
+        auto total = [&](int j) { return ((part[(0 * 9 + j) * 64 + e] + part[(1 * 9 + j) * 64 + e]) + part[(2 * 9 + j) * 64 + e]) + part[(3 * 9 + j) * 64 + e]; };
+        const uint32_t slot = __float_as_uint(stream_rec[(size_t)(p0 + e) * GSR_STREAM_DWORDS + 9]);
         float4 *dst = reinterpret_cast<float4 *>(pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS);
-        dst[c] = c == 0 ? make_float4(val[0], val[1], val[2], val[3])
-                        : (c == 1 ? make_float4(val[4], val[5], val[6], val[7]) : make_float4(val[8], 0.f, 0.f, 0.f));
+        dst[q] = q == 0 ? make_float4(total(0), total(1), total(2), total(3))
+                        : (q == 1 ? make_float4(total(4), total(5), total(6), total(7)) : make_float4(total(8), 0.f, 0.f, 0.f));
     }
 }
 
@@ -340,7 +366,7 @@ extern "C" int gsr_block_lists_supported(const gsr_view *view_host, uint32_t num
     const unsigned long long S2 = (unsigned long long)(L / 16) * (unsigned long long)(L / 16);
     // rows and records are numbered in 26 bits (a run's index rides above six bits of its entries' positions, and the
     // record stream of the blocks must stay below 4 GiB)
-    return (unsigned long long)num_pairs * S2 < (1ull << 26) ? 1 : 0;
+    return (unsigned long long)num_pairs * S2 < (1ull << 26) - 1ull ? 1 : 0;
 }
 
 extern "C" uint32_t gsr_block_count(const gsr_view *view_host)
@@ -401,17 +427,22 @@ extern "C" int gsr_block_lists(const gsr_view *view_host, const uint32_t *tile_o
 }
 
 extern "C" int gsr_block_rows_reduce(const gsr_view *view_host, uint32_t num_pairs, const float *stream_rec, const uint32_t *combo,
-                                     const float *rows, const float *run_sums, float *pairgrad, void *stream)
+                                     const float *block_grad, float *pairgrad, void *stream)
 {
     ViewK v;
     if (int e = gsr_make_view(view_host, &v)) return e;
     if (num_pairs == 0) return GSR_OK;
-    if (!gsr_block_lists_supported(view_host, num_pairs) || !stream_rec || !combo || !rows || !run_sums || !pairgrad) {
+    if (!gsr_block_lists_supported(view_host, num_pairs) || !stream_rec || !combo || !block_grad || !pairgrad) {
         gsr_set_error("gsr_block_rows_reduce: bad arguments");
         return GSR_ERR_ARG;
     }
     const BlockGrid g = block_grid(v);
-    hipLaunchKernelGGL(block_rows_reduce_kernel, dim3(gsr_div_up(num_pairs, 16)), dim3(256), 0, (hipStream_t)stream, g.S2, num_pairs,
-                       stream_rec, combo, rows, run_sums, pairgrad);
+    const dim3 grid(gsr_div_up(num_pairs, 64)), block(256);
+    if (g.S == 2)
+        hipLaunchKernelGGL(block_rows_reduce_kernel<4>, grid, block, 0, (hipStream_t)stream, num_pairs, stream_rec, combo, block_grad, pairgrad);
+    else if (g.S == 3)
+        hipLaunchKernelGGL(block_rows_reduce_kernel<9>, grid, block, 0, (hipStream_t)stream, num_pairs, stream_rec, combo, block_grad, pairgrad);
+    else
+        hipLaunchKernelGGL(block_rows_reduce_kernel<16>, grid, block, 0, (hipStream_t)stream, num_pairs, stream_rec, combo, block_grad, pairgrad);
     return gsr_check_launch("block_rows_reduce");
 }

@@ -416,13 +416,13 @@ __device__ inline RecordLanes record_lanes(int lane)
 //               the per-Gaussian sums add them in row order.  No atomics: the result does not depend on timing.
 //               (Small workgroups, several per compute unit: while one waits at its barrier the others run.)
 //   kAtomic:    more than 16 blocks per tile: independent waves add into a zeroed pairgrad with float atomics.
-//   kBlockRuns: the per-block streams of blocklists.hip: as kOneBlock, the record of an evaluated entry goes to the row its
-//               stream record names; a run record stores the run's colour sums (six floats) in its row of `run_sums`.
+//   kBlockRuns: the per-block streams of blocklists.hip: as kOneBlock, with one row per STREAM record (the record carries its
+//               own index): twelve floats for an evaluated entry, the run's six colour sums for a run record.
 enum StoreMode { kOneBlock = 0, kAtomic = 1, kTileGroup = 2, kBlockRuns = 3 };
 constexpr bool one_block_layout(int mode) { return mode == kOneBlock || mode == kBlockRuns; }
 // the lanes of kFullWriters that hold a colour float of a full record (floats 6..11: lanes 48, 56 and 1, 17, 33, 49)
 constexpr unsigned long long kRunWriters = (1ull << 48) | (1ull << 56) | (1ull << 1) | (1ull << 17) | (1ull << 33) | (1ull << 49);
-constexpr uint32_t kRunSumFloats = 8;   // red, green, four partial sums of blue, two unused
+
 constexpr uint32_t kGroupChunk = 32;   // entries between two reductions of a tile group (two chunk buffers; 16 to 64 time alike)
 constexpr uint32_t kGroupMaxWaves = 4;
 
@@ -525,7 +525,7 @@ template <bool CHECK, int MODE>
 __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ stream_rec, const float pxf,
                                  const f2 (&pyf)[2], f2 (&T)[2], const f2 (&gr)[2], const f2 (&gg)[2],
                                  const f2 (&gb)[2], const uint32_t (&nstop)[4],
-                                 float *__restrict__ pairgrad, float *__restrict__ run_sums, GroupSlot gs)
+                                 float *__restrict__ pairgrad, GroupSlot gs)
 {
     f2 suffix[2] = {splat(0.f), splat(0.f)};
     const f2 py_top = pyf[0];
@@ -650,17 +650,16 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         const float red = R_r(R);
         if (MODE == kBlockRuns && flags == kLowBoth) {
             // a run: U in front of it = U behind it / 0.99^n; the entries' colour gradients follow from it elsewhere
-            const uint32_t run_off = rec_slot<true>(R.d) * (uint32_t)(kRunSumFloats * sizeof(float));
             if (CHECK) {
                 half_low(0, R, k, red, true, true, true);
                 half_low(1, R, k, red, false, true, true);
                 const float val = reduce_full(lanes, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, hsum(s_r), hsum(s_g), hsum(s_b));
-                put_record<kOneBlock>(run_sums, run_off, lanes.full_off - 24u, val, kRunWriters, gs);
+                put_record<kOneBlock>(pairgrad, rec_off, lanes.full_off - 24u, val, kRunWriters, gs);
             } else {
                 half_low(0, R, k, red, true, false, true);
                 half_low(1, R, k, red, false, false, true);
                 U = U * R_rcpP(R);
-                put_record<kOneBlock>(run_sums, run_off, lanes.full_off - 24u, U, kRunWriters, gs);
+                put_record<kOneBlock>(pairgrad, rec_off, lanes.full_off - 24u, U, kRunWriters, gs);
             }
             return;
         }
@@ -778,7 +777,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                                                             const float *__restrict__ stream_rec,
                                                             const float *__restrict__ final_T,
                                                             const float *__restrict__ dimg,
-                                                            float *__restrict__ pairgrad, float *__restrict__ run_sums)
+                                                            float *__restrict__ pairgrad)
 {
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
@@ -873,7 +872,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             const bool inside = w.vx && (w.y0 + 4 * j) < w.ylim;
             if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
         }
-        bwd_sweep<true, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, run_sums, gs);
+        bwd_sweep<true, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, gs);
     } else {
         // Between kTinyT and the smallest normal number the plain sweep still works on a transmittance
         // scaled up by a power of two (exact).  Everything the sweep accumulates is a product of one
@@ -886,7 +885,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 gr[h] = gr[h] * splat(1.0f / kRescue); gg[h] = gg[h] * splat(1.0f / kRescue); gb[h] = gb[h] * splat(1.0f / kRescue);
             }
         }
-        bwd_sweep<false, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, run_sums, gs);
+        bwd_sweep<false, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, gs);
     }
 }
 
@@ -936,15 +935,15 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
     if (S > 4) {
         (void)hipMemsetAsync(pairgrad, 0, (size_t)num_pairs * GSR_PAIRGRAD_FLOATS * sizeof(float), (hipStream_t)stream);
         hipLaunchKernelGGL((composite_bwd_kernel<kAtomic>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
-                           stream_rec, final_T, dimg, pairgrad, (float *)nullptr);
+                           stream_rec, final_T, dimg, pairgrad);
     } else if (S > 1) {
         // S * S / group_waves(S) workgroups per tile, one wave per block of the tile
         const int G = group_waves(S);
         hipLaunchKernelGGL((composite_bwd_kernel<kTileGroup>), dim3((unsigned)v.T * (unsigned)(S * S / G)), dim3(64 * G), 0,
-                           (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, final_T, dimg, pairgrad, (float *)nullptr);
+                           (hipStream_t)stream, v, tile_offsets, tile_order, stream_rec, final_T, dimg, pairgrad);
     } else {
         hipLaunchKernelGGL((composite_bwd_kernel<kOneBlock>), grid, block, 0, (hipStream_t)stream, v, tile_offsets, tile_order,
-                           stream_rec, final_T, dimg, pairgrad, (float *)nullptr);
+                           stream_rec, final_T, dimg, pairgrad);
     }
     return gsr_check_launch("composite_bwd");
 }
@@ -976,16 +975,16 @@ extern "C" int gsr_composite_blocks_fwd(const gsr_view *view_host, uint32_t num_
 
 extern "C" int gsr_composite_blocks_bwd(const gsr_view *view_host, uint32_t num_pairs, const uint32_t *block_offsets,
                                         const uint32_t *block_order, const float *block_stream, const float *final_T,
-                                        const float *dimg, float *rows, float *run_sums, void *stream)
+                                        const float *dimg, float *block_grad, void *stream)
 {
     ViewK v;
     if (int e = blocks_view(view_host, num_pairs, &v, "gsr_composite_blocks_bwd")) return e;
     if (num_pairs == 0) return GSR_OK;
-    if (!block_offsets || !block_stream || !final_T || !dimg || !rows || !run_sums) {
+    if (!block_offsets || !block_stream || !final_T || !dimg || !block_grad) {
         gsr_set_error("gsr_composite_blocks_bwd: null pointer");
         return GSR_ERR_ARG;
     }
     hipLaunchKernelGGL((composite_bwd_kernel<kBlockRuns>), dim3(gsr_div_up((unsigned)v.T, WAVES_PER_BLOCK)), dim3(64 * WAVES_PER_BLOCK), 0,
-                       (hipStream_t)stream, v, block_offsets, block_order, block_stream, final_T, dimg, rows, run_sums);
+                       (hipStream_t)stream, v, block_offsets, block_order, block_stream, final_T, dimg, block_grad);
     return gsr_check_launch("composite_blocks_bwd");
 }

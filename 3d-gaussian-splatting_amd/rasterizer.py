@@ -358,19 +358,17 @@ class BlockLists:
         self.offsets, self.order, self.stream, self.combo, self.cview16 = offsets, order, stream, combo, cview16
 
 
-def block_lists_enabled(tile_length: int) -> bool:
-    """Whether a view of this tile edge is composited from per-block lists when the library supports it.  By default
-    the edges 48 and 64, where it is 1.5 to 1.8 times as fast as the tile-group kernels; at 32 the two are level (628
-    against 622 renders/s at 1 M Gaussians, 1080p) and the tile groups need less memory.  ``GSR_BLOCK_LISTS=0``: never;
-    ``GSR_BLOCK_LISTS=all``: every supported edge (read at every call: tests compare the paths inside one process)."""
-    mode = os.environ.get("GSR_BLOCK_LISTS", "1")
-    return mode != "0" and (tile_length >= 48 or mode == "all")
+def block_lists_enabled() -> bool:
+    """``GSR_BLOCK_LISTS=0`` keeps tiles of several blocks on the tile-group kernels (read at every call: tests compare
+    the two paths inside one process).  By default every tile edge the library supports (32, 48, 64) takes the per-block
+    lists: 1.1, 1.6 and 1.9 times the rate of the tile groups at 1 M Gaussians, 1080p."""
+    return os.environ.get("GSR_BLOCK_LISTS", "1") != "0"
 
 
 def _block_lists_of(st: RenderState) -> RenderState:
     """Builds ``st.blocks`` when the view qualifies (tile edge 32, 48 or 64, few enough pairs); else leaves it None."""
     st.blocks = None
-    if not st.num_visible or not st.num_pairs or not block_lists_enabled(st.view.tile_length):
+    if not st.num_visible or not st.num_pairs or not block_lists_enabled():
         return st
     lib = _lib.load()
     cv, I = st.cview, st.num_pairs
@@ -532,12 +530,11 @@ def _composite_bwd(lib, st: RenderState, dimg, dev) -> torch.Tensor:
     b, I = st.blocks, st.num_pairs
     S2 = (st.view.tile_length // 16) ** 2
     f32 = dict(dtype=torch.float32, device=dev)
-    rows = torch.empty(max(I, 1) * S2, _lib.PAIRGRAD_FLOATS, **f32)     # written where a block evaluates an entry
-    run_sums = torch.empty(max(I, 1) * S2, 8, **f32)                    # one row per run record (upper bound)
+    block_grad = torch.empty(max(I, 1) * S2, _lib.PAIRGRAD_FLOATS, **f32)     # one row per stream record (upper bound)
     _call("gsr_composite_blocks_bwd", lib.gsr_composite_blocks_bwd, st.cview, I, _ptr(b.offsets), _ptr(b.order), _ptr(b.stream),
-          _ptr(st.final_T), _ptr(dimg), _ptr(rows), _ptr(run_sums), stream)
-    _call("gsr_block_rows_reduce", lib.gsr_block_rows_reduce, st.cview, I, _ptr(st.stream_rec), _ptr(b.combo), _ptr(rows),
-          _ptr(run_sums), _ptr(pairgrad), stream)
+          _ptr(st.final_T), _ptr(dimg), _ptr(block_grad), stream)
+    _call("gsr_block_rows_reduce", lib.gsr_block_rows_reduce, st.cview, I, _ptr(st.stream_rec), _ptr(b.combo), _ptr(block_grad),
+          _ptr(pairgrad), stream)
     return pairgrad
 
 

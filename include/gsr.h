@@ -305,22 +305,23 @@ int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, c
  * An entry that does not reach a block of its tile has alpha = 0.01 on all of the block's pixels; a run of n such
  * entries multiplies the block's transmittance by 0.99^n and adds transmittance x (sum_i 0.99^i 0.01 c_i) to its
  * colour - two constants that do not depend on the pixel.  gsr_block_lists rewrites the stream of a view, per block,
- * as the entries the block evaluates plus ONE record per run (runs end at multiples of 64 list positions), in the
+ * as the entries the block evaluates plus ONE record per run (runs end at multiples of 32 list positions), in the
  * record layout of one-block tiles, and the kernels of one-block tiles composite these streams.  Results agree with
  * gsr_composite_fwd / gsr_composite_bwd to rounding (the product 0.99^n is formed in another order); the gradients
  * are reproducible run to run.
- *   gsr_block_lists_supported   1 for tile_length 32 / 48 / 64 with num_pairs x blocks-per-tile < 2^26, else 0
+ *   gsr_block_lists_supported   1 for tile_length 32 / 48 / 64 with num_pairs x blocks-per-tile < 2^26 - 1, else 0
  *   gsr_block_count             T16 = ceil(width / 16) * ceil(height / 16); block id = Y16 + ceil(height / 16) * X16
  *   gsr_block_lists             from tile_offsets and stream_rec of gsr_bin_lists: block_offsets[T16 + 1],
- *                               block_stream[R, 16] (R <= num_pairs x S^2 records, S = tile_length / 16: allocate that),
- *                               combo[num_pairs x S^2] (per list position and block: evaluated / outside the image /
- *                               run << 6 | index inside the run).  gsr_tile_order with tile_length = 16 orders the blocks.
+ *                               block_stream[R, 16] (R <= num_pairs x S^2 records, S = tile_length / 16: allocate that;
+ *                               every record carries its own index r), combo[num_pairs x S^2] (per list position and
+ *                               block: 0xFFFFFFFF outside the image, r << 6 | 32 evaluated by record r, r << 6 | index
+ *                               inside run r).  gsr_tile_order with tile_length = 16 orders the blocks.
  *   gsr_composite_blocks_fwd    img, final_T as gsr_composite_fwd
- *   gsr_composite_blocks_bwd    rows[num_pairs x S^2, 12]: the gradient record of list position p in block c at row
- *                               p S^2 + c, written for evaluated combinations only; run_sums[R, 8]: per run record the
- *                               sums over the block of (transmittance in front of the run) x cotangent
+ *   gsr_composite_blocks_bwd    block_grad[R, 12] (allocate num_pairs x S^2 rows): row r belongs to stream record r -
+ *                               the gradient record of an evaluated entry, or, for a run, the six sums over the block
+ *                               of (transmittance in front of the run) x cotangent (red, green, four parts of blue)
  *   gsr_block_rows_reduce       pairgrad[num_pairs, 12] at the pairs' emission slots, ONE row per pair (sum over the
- *                               blocks in block order, plus 0.01 x 0.99^i x run sum for the blocks on which the entry
+ *                               blocks in a fixed order, plus 0.01 x 0.99^i x run sum for the blocks on which the entry
  *                               was inside a run): what gsr_pair_reduce takes with parts = 1 */
 int gsr_block_lists_supported(const gsr_view *view_host, uint32_t num_pairs);
 uint32_t gsr_block_count(const gsr_view *view_host);
@@ -332,9 +333,9 @@ int gsr_composite_blocks_fwd(const gsr_view *view_host, uint32_t num_pairs, cons
                              const uint32_t *block_order, const float *block_stream, float *img, float *final_T, void *stream);
 int gsr_composite_blocks_bwd(const gsr_view *view_host, uint32_t num_pairs, const uint32_t *block_offsets,
                              const uint32_t *block_order, const float *block_stream, const float *final_T, const float *dimg,
-                             float *rows, float *run_sums, void *stream);
+                             float *block_grad, void *stream);
 int gsr_block_rows_reduce(const gsr_view *view_host, uint32_t num_pairs, const float *stream_rec, const uint32_t *combo,
-                          const float *rows, const float *run_sums, float *pairgrad, void *stream);
+                          const float *block_grad, float *pairgrad, void *stream);
 
 /* ---- training loss of one view ----------------------------------------------------------
  * Replaces Trainer.compute_loss (Trainer.py:35-38) with its two terms l1_loss (Utils/Loss.py:4-5)

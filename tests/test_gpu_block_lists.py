@@ -18,7 +18,7 @@ from util import assert_close, grad_tolerance  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GRADS = ("g_coords", "g_scale", "g_rotation", "g_opacity", "g_sh", "g_screen")
-EVALUATED, OUTSIDE = 0xFFFFFFFF, 0xFFFFFFFE
+OUTSIDE, EVALUATED_BIT = 0xFFFFFFFF, 32
 
 
 @pytest.fixture(autouse=True)
@@ -33,7 +33,7 @@ def _restore_switch():
 
 def _render(p, view, cot, blocks):
     from gsplat_amd import rasterizer as R
-    os.environ["GSR_BLOCK_LISTS"] = "all" if blocks else "0"
+    os.environ["GSR_BLOCK_LISTS"] = "1" if blocks else "0"
     st = R.forward_pipeline(*p, None, view)
     grads = R.backward_pipeline(st, *p, cot)
     torch.cuda.synchronize()
@@ -66,7 +66,7 @@ def test_block_lists_equal_the_tile_groups(kind, n, W, H, deg, tile):
     if kind == "opaque":
         # pixels whose transmittance underflows: their waves take the checked sweep of the backward, through runs too
         combo = b.blocks.combo.cpu().numpy().view(np.uint32)
-        assert bool((b.final_T < 1.1754944e-38).any()) and bool((combo < OUTSIDE).any())
+        assert bool((b.final_T < 1.1754944e-38).any()) and bool(((combo != OUTSIDE) & ((combo & EVALUATED_BIT) == 0)).any())
     # forward: only the order of the roundings differs
     assert_close(b.img.cpu().numpy(), a.img.cpu().numpy(), "img", rtol=2e-5)
     assert_close(b.final_T.cpu().numpy(), a.final_T.cpu().numpy(), "final_T", rtol=2e-5)
@@ -77,13 +77,13 @@ def test_block_lists_equal_the_tile_groups(kind, n, W, H, deg, tile):
 @pytest.mark.parametrize("tile,W,H", [(64, 330, 210), (48, 330, 210), (32, 200, 120)])
 def test_block_streams_follow_the_hint_flags(tile, W, H):
     """Every (list position, block) combination is either evaluated - then the block's stream holds the entry's record,
-    in list order, with the entry's row - or inside a run of entries whose two hint bits for that block are set; a run
+    in list order, with its own index - or inside a run of entries whose two hint bits for that block are set; a run
     record carries 0.99^n and the run's colour; blocks beyond the image's edge have no stream."""
     from gsplat_amd import rasterizer as R
     dev = torch.device("cuda:0")
     sc = _scene("adv", 20000, W, H, 1, 9)
     p = [t.to(dev) for t in sc.params()]
-    os.environ["GSR_BLOCK_LISTS"] = "all"
+    os.environ["GSR_BLOCK_LISTS"] = "1"
     st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, tile))
     torch.cuda.synchronize()
     assert st.blocks is not None
@@ -116,7 +116,8 @@ def test_block_streams_follow_the_hint_flags(tile, W, H):
             lo, hi = int(boff[blk]), int(boff[blk + 1])
             seen_records += hi - lo
             clamped = ((flags[b:e] >> (2 * c)) & 3) == 3
-            assert np.array_equal(col == EVALUATED, ~clamped), "evaluated exactly where the hint bits are not both set"
+            assert np.all(col != OUTSIDE)
+            assert np.array_equal((col & EVALUATED_BIT) != 0, ~clamped), "evaluated exactly where the hint bits are not both set"
             # walk the list: expected records of this block
             expect = []          # ("e", position) or ("r", first position, length)
             k = b
@@ -126,7 +127,7 @@ def test_block_streams_follow_the_hint_flags(tile, W, H):
                     k += 1
                     continue
                 end = k
-                chunk_end = b + ((k - b) // 64 + 1) * 64          # runs end at multiples of 64 list positions of the tile
+                chunk_end = b + ((k - b) // 32 + 1) * 32          # runs end at multiples of 32 list positions of the tile
                 while end < e and end < chunk_end and clamped[end - b]:
                     end += 1
                 expect.append(("r", k, end - k))
@@ -136,7 +137,8 @@ def test_block_streams_follow_the_hint_flags(tile, W, H):
                 if x[0] == "e":
                     pos = x[1]
                     assert not is_run[r]
-                    assert (word9[r] & 0x3FFFFFFF) == pos * S2 + c and (word9[r] >> 30) == ((flags[pos] >> (2 * c)) & 3)
+                    assert (word9[r] & 0x3FFFFFFF) == r and (word9[r] >> 30) == ((flags[pos] >> (2 * c)) & 3)
+                    assert col[pos - b] == ((r << 6) | EVALUATED_BIT)
                     assert np.array_equal(brec[r, :9].view(np.uint32), tile_rec[pos, :9].view(np.uint32))   # y x D' A' o B' r ca g
                     assert brec[r, 10] == tile_rec[pos, 10] and brec[r, 12] == tile_rec[pos, 12] and brec[r, 14] == tile_rec[pos, 14]
                     assert brec[r, 11] == np.float32(0.01) * tile_rec[pos, 10]
@@ -164,17 +166,15 @@ def test_views_that_keep_the_tile_groups():
     p = [t.to(dev) for t in sc.params()]
     lib = _lib.load()
     for tile, want in ((16, False), (40, False), (80, False), (32, True), (48, True), (64, True)):
-        for mode in ("1", "all"):
-            os.environ["GSR_BLOCK_LISTS"] = mode
-            st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, tile))
-            used = want and (mode == "all" or tile >= 48)        # (by default only where it is faster: edges 48 and 64)
-            assert (st.blocks is not None) == used
-            assert bool(lib.gsr_block_lists_supported(st.cview, st.num_pairs)) == want
-            assert R.pairgrad_parts(st) == (1 if used else int(lib.gsr_pairgrad_parts(tile)))
+        os.environ["GSR_BLOCK_LISTS"] = "1"
+        st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, tile))
+        assert (st.blocks is not None) == want
+        assert bool(lib.gsr_block_lists_supported(st.cview, st.num_pairs)) == want
+        assert R.pairgrad_parts(st) == (1 if want else int(lib.gsr_pairgrad_parts(tile)))
     os.environ["GSR_BLOCK_LISTS"] = "0"
     st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, 64))
     assert st.blocks is None
-    assert not lib.gsr_block_lists_supported(st.cview, 1 << 22)        # 2^22 pairs x 16 blocks = 2^26: too many rows
+    assert not lib.gsr_block_lists_supported(st.cview, 1 << 22)        # 2^22 pairs x 16 blocks = 2^26: too many records
     assert lib.gsr_block_lists_supported(st.cview, (1 << 22) - 1)
 
 

@@ -46,7 +46,7 @@ def main():
     off = b.blocks.offsets.cpu().long()
     R_total = int(off[-1])
     combo = b.blocks.combo.cpu().long() & 0xFFFFFFFF
-    ev, outside = int((combo == 0xFFFFFFFF).sum()), int((combo == 0xFFFFFFFE).sum())
+    ev, outside = int(((combo != 0xFFFFFFFF) & ((combo & 32) != 0)).sum()), int((combo == 0xFFFFFFFF).sum())
     print(f"{n} Gaussians {W}x{H} tile {tile}: {b.num_pairs} pairs, {len(off) - 1} blocks, {R_total} block records "
           f"({R_total / max(b.num_pairs * S2 - outside, 1):.3f} of the pair-block combinations), evaluated {ev}, outside {outside}")
     assert bool((off[1:] >= off[:-1]).all())
