@@ -78,3 +78,23 @@ def test_bin_lists_refuses_a_record_stream_of_4_gib():
     assert rc == -1          # GSR_ERR_ARG
     with pytest.raises(RuntimeError, match="4 GiB"):
         _lib.check(rc, "bin_lists")
+
+
+def test_block_list_queries_do_not_need_a_gpu():
+    """Which views take the per-block lists, how many blocks they have and how much scratch the builder wants."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd import _lib
+    lib = _lib.load()
+    eye = [1.0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+
+    def view(tile):
+        return _lib.make_view(1000, 3, 1920, 1080, tile, eye, eye, [0.0, 0.0, 0.0])
+
+    for tile, want in ((16, 0), (32, 1), (40, 0), (48, 1), (64, 1), (80, 0), (128, 0)):
+        assert lib.gsr_block_lists_supported(view(tile), 100_000) == want
+    assert lib.gsr_block_lists_supported(view(64), (1 << 22) - 1) == 1       # pairs x 16 blocks must stay below 2^26 - 1
+    assert lib.gsr_block_lists_supported(view(64), 1 << 22) == 0
+    assert lib.gsr_block_lists_supported(view(32), (1 << 24) - 1) == 1
+    assert lib.gsr_block_count(view(64)) == 120 * 68
+    tiles = 30 * 17
+    assert lib.gsr_block_lists_workspace_bytes(view(64), 1_000_000) >= 4 * (16 * (1_000_000 // 64 + tiles) + tiles + 120 * 68)

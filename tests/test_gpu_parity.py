@@ -179,15 +179,17 @@ def test_config1_like_50k_deg0_180x180_vs_oracle(oracle_mod, tile):
     compare(hip, ora)
 
 
-def test_config2_200k_800x800_vs_oracle(oracle_mod):
-    """The single-view parity configuration: 200k Gaussians, SH degree 3, one 800x800 view, forward + backward."""
+@pytest.mark.parametrize("tile", [16, 64])
+def test_config2_200k_800x800_vs_oracle(oracle_mod, tile):
+    """The single-view parity configuration: 200k Gaussians, SH degree 3, one 800x800 view, forward + backward; at a
+    tile edge of 16 and at the reference's default of 64 (per-block lists)."""
     import gsplat_amd  # noqa: F401
     from gsplat_amd.scenes import synthetic_scene
     sc = synthetic_scene(200_000, 800, 800, 3, 0)
     a = _scene_arrays(sc)
     cot = torch.rand(800, 800, 3, generator=torch.Generator().manual_seed(7)).numpy()
-    hip = run_hip(cot=cot, tile=16, **a)
-    ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 3, 800, 800, 16, a["w2m"],
+    hip = run_hip(cot=cot, tile=tile, **a)
+    ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 3, 800, 800, tile, a["w2m"],
                             a["proj"], a["cam_pos"], dimg=cot)
     compare(hip, ora)
 
