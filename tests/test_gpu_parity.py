@@ -330,6 +330,20 @@ def test_config3_1m_1080p_vs_oracle(oracle_mod):
     assert np.array_equal(np.bincount(lst, minlength=len(bb)), (nx * ny) * hip["mask"])
 
 
+def test_config3_view_at_the_default_tile_edge_vs_oracle(oracle_mod):
+    """One view of the headline configuration (1 M Gaussians, 1920x1080) at the reference's default tile edge of 64
+    (Trainer.py:55 calls the renderer without a tile edge), forward + backward: the per-block lists at full size."""
+    import gsplat_amd  # noqa: F401
+    from gsplat_amd.scenes import synthetic_scene
+    sc = synthetic_scene(1_000_000, 1920, 1080, 3, 0)
+    a = _scene_arrays(sc)
+    cot = torch.rand(1920, 1080, 3, generator=torch.Generator().manual_seed(7)).numpy()
+    hip = run_hip(cot=cot, tile=64, **a)
+    ora = oracle_mod.render(a["coords"], a["scale"], a["rotation"], a["opacity"], a["sh"], 3, 1920, 1080, 64,
+                            a["w2m"], a["proj"], a["cam_pos"], dimg=cot)
+    compare(hip, ora)
+
+
 def test_config5_6m_4k_forward_vs_oracle(oracle_mod):
     """The forward-only stress configuration, one view at full size: 6 M Gaussians, 3840x2160, tile 16, forward
     only (32 M pairs, a 2 GiB record stream): discrete results bit-exact, the image within tolerance."""
