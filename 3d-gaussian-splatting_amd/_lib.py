@@ -32,7 +32,7 @@ SYMBOLS = (
     "gsr_bin_lists_workspace_bytes", "gsr_bin_lists", "gsr_tile_order", "gsr_bin_lists_views_supported",
     "gsr_bin_lists_views_layout", "gsr_bin_lists_views_workspace_bytes", "gsr_bin_lists_views",
     "gsr_composite_fwd", "gsr_composite_bwd", "gsr_pairgrad_parts",
-    "gsr_block_lists_supported", "gsr_block_count", "gsr_block_lists_workspace_bytes", "gsr_block_lists",
+    "gsr_block_lists_supported", "gsr_block_combo_bytes", "gsr_block_count", "gsr_block_lists_workspace_bytes", "gsr_block_lists",
     "gsr_composite_blocks_fwd", "gsr_composite_blocks_bwd", "gsr_block_rows_reduce",
     "gsr_loss_workspace_bytes", "gsr_loss_fwd_bwd",
     "gsr_adam_step", "gsr_knn_dist2",
@@ -129,6 +129,8 @@ def load():
     lib.gsr_composite_fwd.argtypes = [C.POINTER(GsrView), vp, vp, vp, vp, vp, vp]
     lib.gsr_block_lists_supported.argtypes = [C.POINTER(GsrView), C.c_uint32]
     lib.gsr_block_count.restype = C.c_uint32
+    lib.gsr_block_combo_bytes.restype = C.c_uint32
+    lib.gsr_block_combo_bytes.argtypes = [C.POINTER(GsrView), C.c_uint32]
     lib.gsr_block_count.argtypes = [C.POINTER(GsrView)]
     lib.gsr_block_lists_workspace_bytes.restype = C.c_size_t
     lib.gsr_block_lists_workspace_bytes.argtypes = [C.POINTER(GsrView), C.c_uint32]

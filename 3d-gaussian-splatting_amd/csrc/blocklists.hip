@@ -17,16 +17,21 @@
 // Outputs, for a view of T16 = ceil(W/16) * ceil(H/16) blocks (block id = Y16 + ceil(H/16) * X16, the tile id of the
 // same view at a tile edge of 16):
 //   block_offsets[T16 + 1]  range of each block's records in block_stream
-//   block_stream[R, 16]     the records; every record carries its own index r, which is also the row the compositing
-//                           backward writes for it: a wave's stores follow its walk through the stream
-//   combo[I * S^2]          per list position p and block c: 0xFFFFFFFF = the block lies outside the image, else
-//                           r << 6 | 32 = the block evaluates the entry (record r), or r << 6 | index inside run r
+//   block_stream[R, 16]     the records; every record carries its index inside its block's stream - the compositing
+//                           backward writes row r (the record's position in block_stream) for it, so a wave's stores
+//                           follow its walk through the stream
+//   combo[I * S^2]          per list position p and block c (32-bit words, 64-bit ones from 2^26 - 1 combinations on):
+//                           all ones = the block lies outside the image, else r << 6 | 32 = the block evaluates the entry
+//                           (record r), or r << 6 | index inside run r
 #include "gsr_common.hpp"
+
+#include <stdlib.h>
 
 namespace {
 
 constexpr uint32_t kChunk = 64;
-constexpr uint32_t kOutside = 0xFFFFFFFFu, kEvaluatedBit = 32u, kRunIndexMask = 31u;
+constexpr uint32_t kEvaluatedBit = 32u, kRunIndexMask = 31u;
+template <class W> __device__ constexpr W outside() { return ~(W)0; }   // combination word of a block outside the image
 constexpr unsigned long long kRunBreaks = (1ull << 32) | 1ull;   // lanes at which a run always starts anew
 constexpr float kAlphaFloor = 0.01f;
 
@@ -165,13 +170,13 @@ struct Pow99 {
 };
 __constant__ Pow99 kPow99 = Pow99();
 
-template <int S>
+template <int S, class W>
 __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_t *__restrict__ tile_offsets,
                                                           const float *__restrict__ stream_rec,
                                                           const uint32_t *__restrict__ chunk_base_tile,
                                                           const uint32_t *__restrict__ chunk_base_block,
                                                           const uint32_t *__restrict__ first_record,   // scanned counts
-                                                          float *__restrict__ block_stream, uint32_t *__restrict__ combo)
+                                                          float *__restrict__ block_stream, W *__restrict__ combo)
 {
     constexpr int S2 = S * S;
     __shared__ float pow99[kChunk + 1];
@@ -198,13 +203,16 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
     const unsigned long long below = (1ull << lane) - 1ull;
     // lane c fetches where block c's records of this chunk start (one dependent load per wave, not one per block)
     const BlockOfTile own = block_of_tile(v, g, t, min(lane, S2 - 1));
-    const uint32_t own_first = (lane < S2 && own.inside) ? first_record[chunk_base_block[own.id] + k] : 0u;
-    uint32_t cmb[S2];   // the entry's word of every block: stored together after the loop (S2 consecutive words per entry)
+    const bool owner = lane < S2 && own.inside;
+    const uint32_t own_first = owner ? first_record[chunk_base_block[own.id] + k] : 0u;
+    const uint32_t own_block_first = owner ? first_record[chunk_base_block[own.id]] : 0u;   // the block's first record
+    W cmb[S2];   // the entry's word of every block: stored together after the loop (S2 consecutive words per entry)
 #pragma unroll
     for (int c = 0; c < S2; ++c) {
         const BlockOfTile b = block_of_tile(v, g, t, c);
         const uint32_t first = (uint32_t)__shfl((int)own_first, c, 64);
-        cmb[c] = kOutside;
+        const uint32_t block_first = (uint32_t)__shfl((int)own_block_first, c, 64);
+        cmb[c] = outside<W>();
         if (!b.inside) continue;
         const uint32_t f = (flags >> (2 * c)) & 3u;
         const bool clamped = valid && f == 3u;
@@ -225,13 +233,14 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
             if (idx >= d) { sr += r1; sg += g1; sb += b1; }
         }
         const bool last = clamped && (lane == 63 || !((joined >> (lane + 1)) & 1ull));
-        if (valid) cmb[c] = clamped ? (rid << 6) | (uint32_t)idx : (rid << 6) | kEvaluatedBit;
+        if (valid) cmb[c] = ((W)rid << 6) | (W)(clamped ? (uint32_t)idx : kEvaluatedBit);
+        const uint32_t local = rid - block_first;   // the record's index in its block's stream
         if (valid && (!clamped || last)) {
             float4 *at = wave_staged + (rid - first) * 4u;
             if (!clamped) {
                 // the entry's own record in the layout of a one-block tile: ... | g index+flags b b/100 | cbh r/100 cd g/100
                 at[0] = q0; at[1] = q1;
-                at[2] = make_float4(green, __uint_as_float(rid | (f << 30)), blue, kAlphaFloor * blue);
+                at[2] = make_float4(green, __uint_as_float(local | (f << 30)), blue, kAlphaFloor * blue);
                 at[3] = make_float4(q3.x, kAlphaFloor * red, q3.z, kAlphaFloor * green);
             } else {
                 // a run: dword 4 = 0.99^n, dword 5 = its reciprocal, dword 9 = the record's own index with both hint bits
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
                 const float P = pow99[idx + 1];
                 at[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                 at[1] = make_float4(P, 1.0f / P, 0.f, 0.f);
-                at[2] = make_float4(0.f, __uint_as_float(rid | (3u << 30)), 0.f, sb);
+                at[2] = make_float4(0.f, __uint_as_float(local | (3u << 30)), 0.f, sb);
                 at[3] = make_float4(0.f, sr, 0.f, sg);
             }
         }
@@ -252,10 +261,16 @@ __global__ __launch_bounds__(256) void block_write_kernel(ViewK v, const uint32_
         __builtin_amdgcn_wave_barrier();
     }
     if (valid) {
-        uint32_t *dst = combo + (size_t)p * (size_t)S2;
-        if (S2 % 4 == 0) {
+        W *dst = combo + (size_t)p * (size_t)S2;
+        constexpr int kPerPiece = 16 / (int)sizeof(W);
+        if (S2 % kPerPiece == 0) {
 #pragma unroll
-            for (int c = 0; c < S2; c += 4) reinterpret_cast<uint4 *>(dst)[c / 4] = make_uint4(cmb[c], cmb[c + 1], cmb[c + 2], cmb[c + 3]);
+            for (int c = 0; c < S2; c += kPerPiece) {
+                uint4 piece;
+                if (sizeof(W) == 4) piece = make_uint4((uint32_t)cmb[c], (uint32_t)cmb[c + 1], (uint32_t)cmb[c + 2], (uint32_t)cmb[c + 3]);
+                else piece = make_uint4((uint32_t)cmb[c], (uint32_t)((unsigned long long)cmb[c] >> 32), (uint32_t)cmb[c + 1], (uint32_t)((unsigned long long)cmb[c + 1] >> 32));
+                reinterpret_cast<uint4 *>(dst)[c / kPerPiece] = piece;
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < S2; ++c) dst[c] = cmb[c];
@@ -282,12 +297,12 @@ __global__ __launch_bounds__(256) void block_offsets_kernel(uint32_t T16, const 
 // ...), so that neighbouring lanes - neighbouring entries of a list, which mostly sit in the same run - read the same
 // run sums.  The combination words arrive through LDS (loaded as they lie, read by block), the four waves' partial
 // sums meet in LDS and are added in wave order: fixed orders throughout, the result is reproducible.
-template <int S2>
+template <int S2, class W>
 __global__ __launch_bounds__(256) void block_rows_reduce_kernel(uint32_t num_pairs, const float *__restrict__ stream_rec,
-                                                                const uint32_t *__restrict__ combo,
+                                                                const W *__restrict__ combo,
                                                                 const float *__restrict__ block_grad, float *__restrict__ pairgrad)
 {
-    __shared__ uint32_t words[S2 * 65];        // [block][entry], rows padded to 65
+    __shared__ W words[S2 * 65];               // [block][entry], rows padded to 65
     __shared__ float part[4 * 9 * 64];         // [wave][sum][entry]
     const uint32_t p0 = blockIdx.x * 64u;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -303,27 +318,27 @@ __global__ __launch_bounds__(256) void block_rows_reduce_kernel(uint32_t num_pai
     if ((uint32_t)l < count) {
         // (all loads of the wave's blocks are issued before the first sum)
         constexpr int kTurns = (S2 + 3) / 4;
-        uint32_t m[kTurns];
+        W m[kTurns];
         float4 a[kTurns], b[kTurns], d[kTurns];
 #pragma unroll
         for (int q = 0; q < kTurns; ++q) {
             const int c = w + 4 * q;
-            m[q] = c < S2 ? words[c * 65 + l] : kOutside;
+            m[q] = c < S2 ? words[c * 65 + l] : outside<W>();
             a[q] = b[q] = d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m[q] == kOutside) continue;
+            if (m[q] == outside<W>()) continue;
             const float4 *src = reinterpret_cast<const float4 *>(block_grad + (size_t)(m[q] >> 6) * GSR_PAIRGRAD_FLOATS);
             a[q] = src[0]; b[q] = src[1];                                 // (a run: r g b0 b1 | b2 b3 - -)
             if (m[q] & kEvaluatedBit) d[q] = src[2];
         }
 #pragma unroll
         for (int q = 0; q < kTurns; ++q) {
-            if (m[q] == kOutside) continue;
+            if (m[q] == outside<W>()) continue;
             if (m[q] & kEvaluatedBit) {
                 val[0] += a[q].x; val[1] += a[q].y; val[2] += a[q].z; val[3] += a[q].w;
                 val[4] += b[q].x; val[5] += b[q].y; val[6] += b[q].z; val[7] += b[q].w;
                 val[8] += (d[q].x + d[q].y) + (d[q].z + d[q].w);
             } else {
-                const float wgt = kAlphaFloor * __builtin_amdgcn_exp2f((float)(m[q] & kRunIndexMask) * -0.014499569695115089f);   // 0.01 * 0.99^i
+                const float wgt = kAlphaFloor * __builtin_amdgcn_exp2f((float)((uint32_t)m[q] & kRunIndexMask) * -0.014499569695115089f);   // 0.01 * 0.99^i
                 val[6] = fmaf(wgt, a[q].x, val[6]);
                 val[7] = fmaf(wgt, a[q].y, val[7]);
                 val[8] = fmaf(wgt, (a[q].z + a[q].w) + (b[q].x + b[q].y), val[8]);
@@ -368,15 +383,33 @@ inline Layout layout_of(const ViewK &v, uint32_t num_pairs)
 
 }  // namespace
 
+// pair-block combinations of a view (the upper bound of its block records)
+static unsigned long long combinations(const gsr_view *view_host, uint32_t num_pairs)
+{
+    const unsigned long long S = (unsigned long long)(view_host->tile_length / 16);
+    return (unsigned long long)num_pairs * S * S;
+}
+
+// 64-bit combination words: from 2^26 - 1 combinations on (a record's index rides above six bits), or when
+// GSR_BLOCK_WIDE=1 asks for them (read at every call: a test switches it inside one process)
+static bool wide_words(const gsr_view *view_host, uint32_t num_pairs)
+{
+    const char *e = getenv("GSR_BLOCK_WIDE");
+    return (e && e[0] == '1') || combinations(view_host, num_pairs) >= (1ull << 26) - 1ull;
+}
+
 extern "C" int gsr_block_lists_supported(const gsr_view *view_host, uint32_t num_pairs)
 {
     if (!view_host) return 0;
     const int L = view_host->tile_length;
     if (!(L == 32 || L == 48 || L == 64)) return 0;
-    const unsigned long long S2 = (unsigned long long)(L / 16) * (unsigned long long)(L / 16);
-    // rows and records are numbered in 26 bits (a run's index rides above six bits of its entries' positions, and the
-    // record stream of the blocks must stay below 4 GiB)
-    return (unsigned long long)num_pairs * S2 < (1ull << 26) - 1ull ? 1 : 0;
+    // records are counted in 32 bits and the buffers are sized by the number of combinations: 2^28 of them are 31 GB
+    return combinations(view_host, num_pairs) < (1ull << 28) ? 1 : 0;
+}
+
+extern "C" uint32_t gsr_block_combo_bytes(const gsr_view *view_host, uint32_t num_pairs)
+{
+    return view_host && wide_words(view_host, num_pairs) ? 8u : 4u;
 }
 
 extern "C" uint32_t gsr_block_count(const gsr_view *view_host)
@@ -391,14 +424,42 @@ extern "C" size_t gsr_block_lists_workspace_bytes(const gsr_view *view_host, uin
     return layout_of(v, num_pairs).bytes;
 }
 
+template <class W>
+static void launch_block_write(int S, dim3 grid, dim3 block, hipStream_t s, const ViewK &v, const uint32_t *tile_offsets,
+                               const float *stream_rec, const uint32_t *chunk_base_tile, const uint32_t *chunk_base_block,
+                               const uint32_t *counts, float *block_stream, W *combo)
+{
+    if (S == 2)
+        hipLaunchKernelGGL((block_write_kernel<2, W>), grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
+                           block_stream, combo);
+    else if (S == 3)
+        hipLaunchKernelGGL((block_write_kernel<3, W>), grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
+                           block_stream, combo);
+    else
+        hipLaunchKernelGGL((block_write_kernel<4, W>), grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
+                           block_stream, combo);
+}
+
+template <class W>
+static void launch_rows_reduce(int S, dim3 grid, dim3 block, hipStream_t s, uint32_t num_pairs, const float *stream_rec, const W *combo,
+                               const float *block_grad, float *pairgrad)
+{
+    if (S == 2)
+        hipLaunchKernelGGL((block_rows_reduce_kernel<4, W>), grid, block, 0, s, num_pairs, stream_rec, combo, block_grad, pairgrad);
+    else if (S == 3)
+        hipLaunchKernelGGL((block_rows_reduce_kernel<9, W>), grid, block, 0, s, num_pairs, stream_rec, combo, block_grad, pairgrad);
+    else
+        hipLaunchKernelGGL((block_rows_reduce_kernel<16, W>), grid, block, 0, s, num_pairs, stream_rec, combo, block_grad, pairgrad);
+}
+
 extern "C" int gsr_block_lists(const gsr_view *view_host, const uint32_t *tile_offsets, const float *stream_rec, uint32_t num_pairs,
-                               uint32_t *block_offsets, float *block_stream, uint32_t *combo, void *workspace,
+                               uint32_t *block_offsets, float *block_stream, void *combo, void *workspace,
                                size_t workspace_bytes, void *stream)
 {
     ViewK v;
     if (int e = gsr_make_view(view_host, &v)) return e;
     if (!gsr_block_lists_supported(view_host, num_pairs)) {
-        gsr_set_error("gsr_block_lists: tile edge %d with %u pairs is not supported (edges 32, 48, 64; pairs x blocks per tile < 2^26)",
+        gsr_set_error("gsr_block_lists: tile edge %d with %u pairs is not supported (edges 32, 48, 64; pairs x blocks per tile < 2^28)",
                       view_host->tile_length, num_pairs);
         return GSR_ERR_ARG;
     }
@@ -422,21 +483,18 @@ extern "C" int gsr_block_lists(const gsr_view *view_host, const uint32_t *tile_o
                        chunk_base_block, counts);
     if (int e = gsr_exclusive_scan(counts, counts, l.n_counts, total, ws + l.off_scan, l.scan_bytes, stream)) return e;
     const dim3 grid(gsr_div_up(waves, 4)), block(256);
-    if (g.S == 2)
-        hipLaunchKernelGGL(block_write_kernel<2>, grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
-                           block_stream, combo);
-    else if (g.S == 3)
-        hipLaunchKernelGGL(block_write_kernel<3>, grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
-                           block_stream, combo);
+    if (wide_words(view_host, num_pairs))
+        launch_block_write(g.S, grid, block, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts, block_stream,
+                           static_cast<unsigned long long *>(combo));
     else
-        hipLaunchKernelGGL(block_write_kernel<4>, grid, block, 0, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts,
-                           block_stream, combo);
+        launch_block_write(g.S, grid, block, s, v, tile_offsets, stream_rec, chunk_base_tile, chunk_base_block, counts, block_stream,
+                           static_cast<uint32_t *>(combo));
     hipLaunchKernelGGL(block_offsets_kernel, dim3(gsr_div_up((unsigned)g.T16 + 1u, 256)), dim3(256), 0, s, (uint32_t)g.T16,
                        chunk_base_block, counts, total, block_offsets);
     return gsr_check_launch("block_lists");
 }
 
-extern "C" int gsr_block_rows_reduce(const gsr_view *view_host, uint32_t num_pairs, const float *stream_rec, const uint32_t *combo,
+extern "C" int gsr_block_rows_reduce(const gsr_view *view_host, uint32_t num_pairs, const float *stream_rec, const void *combo,
                                      const float *block_grad, float *pairgrad, void *stream)
 {
     ViewK v;
@@ -448,11 +506,9 @@ extern "C" int gsr_block_rows_reduce(const gsr_view *view_host, uint32_t num_pai
     }
     const BlockGrid g = block_grid(v);
     const dim3 grid(gsr_div_up(num_pairs, 64)), block(256);
-    if (g.S == 2)
-        hipLaunchKernelGGL(block_rows_reduce_kernel<4>, grid, block, 0, (hipStream_t)stream, num_pairs, stream_rec, combo, block_grad, pairgrad);
-    else if (g.S == 3)
-        hipLaunchKernelGGL(block_rows_reduce_kernel<9>, grid, block, 0, (hipStream_t)stream, num_pairs, stream_rec, combo, block_grad, pairgrad);
+    if (wide_words(view_host, num_pairs))
+        launch_rows_reduce(g.S, grid, block, (hipStream_t)stream, num_pairs, stream_rec, static_cast<const unsigned long long *>(combo), block_grad, pairgrad);
     else
-        hipLaunchKernelGGL(block_rows_reduce_kernel<16>, grid, block, 0, (hipStream_t)stream, num_pairs, stream_rec, combo, block_grad, pairgrad);
+        launch_rows_reduce(g.S, grid, block, (hipStream_t)stream, num_pairs, stream_rec, static_cast<const uint32_t *>(combo), block_grad, pairgrad);
     return gsr_check_launch("block_rows_reduce");
 }

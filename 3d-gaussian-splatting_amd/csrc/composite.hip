@@ -45,14 +45,18 @@ struct WaveGeom {
     int tile, x, y0;     // pixel column and first row of this lane; its rows are y0 + 4 j, j = 0..3
     bool vx;             // column inside the tile and the image
     int ylim;            // rows < ylim are inside
-    uint32_t begin, end; // list range (wave-uniform)
-    uint32_t total;      // records in the whole stream
+    uint32_t begin, end; // list range (wave-uniform), RELATIVE to the list's first record: begin = 0, end = its length
+    uint32_t total;      // records from the list's first one to the end of the stream (capped at 2^26 - 1)
+    uint32_t first;      // position of the list's first record in the stream
     uint32_t flag_shift; // position of this block's two hint bits in a record's flags
     uint32_t turn;       // rank of the tile in the order the grid takes the tiles
 };
 
 // tile_order (may be null): the tiles in the order in which the waves of the grid take them - longest
 // lists first, so that the waves still running when the grid drains are short ones.
+// List positions are RELATIVE to the list's first record (w.first): the kernels move their stream pointer there
+// (list_start below), so their 32-bit byte offsets only have to span one list and the touch-ahead behind it - a stream
+// may be longer than 4 GiB.
 __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ tile_offsets,
                                   const uint32_t *__restrict__ tile_order, WaveGeom &w)
 {
@@ -75,9 +79,14 @@ __device__ inline bool wave_setup(const ViewK &v, const uint32_t *__restrict__ t
     const int xlim = min((xi + 1) * v.L, v.W);
     w.ylim = min((yi + 1) * v.L, v.H);
     w.vx = w.x < xlim;
-    w.begin = tile_offsets[tile];
-    w.end = tile_offsets[tile + 1];
-    w.total = tile_offsets[v.T];
+    // (wave-uniform by construction; said explicitly, because the kernels use them as scalar operands of asm statements)
+    const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_offsets[tile]);
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_offsets[tile + 1]);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_offsets[v.T]);
+    w.first = begin;
+    w.begin = 0u;
+    w.end = end - begin;
+    w.total = min(total - begin, (1u << 26) - 1u);
     return true;
 }
 
@@ -158,6 +167,11 @@ __device__ inline const char *uniform_address(const char *p)
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
     return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
 }
+// the stream from the first record of the wave's list on, as a pair of scalar registers
+__device__ inline const float *list_start(const float *stream_rec, const WaveGeom &w)
+{
+    return reinterpret_cast<const float *>(uniform_address(reinterpret_cast<const char *>(stream_rec + (size_t)w.first * GSR_STREAM_DWORDS)));
+}
 // A vector memory instruction must not read a scalar register within five wait states of a VECTOR instruction
 // (v_readfirstlane) writing it.  The compiler inserts those wait states for its own instructions but cannot see
 // into an asm statement, so every asm below whose memory instruction takes such an address starts with them.
@@ -230,6 +244,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(ViewK v, const uint3
 {
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
+    stream_rec = list_start(stream_rec, w);
     raise_wave_priority(w, v.T);
     const float pxf = (float)w.x;
     f2 pyf[2], T[2], cr[2], cg[2], cb[2];   // pixel rows (y0, y0+4): top half, (y0+8, y0+12): bottom half
@@ -697,7 +712,6 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     };
     // back to front, record buffers kept by hand (see composite_fwd_kernel); k is only needed by
     // the checked variant
-    const uint32_t off_first = w.begin * 64u;
     uint32_t off = (w.end - 1) * 64u;   // the caller guarantees a non-empty list
     uint32_t k = w.end - 1;
     // (odd lanes touch the record after the one named; a stream of a single record has none)
@@ -708,7 +722,9 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
     rec_request(stream_rec, off, A);
     if (!CHECK && one_block_layout(MODE)) {
         // plain sweep of a one-block tile: four record buffers, two fetches in flight per wait (see composite_fwd_kernel)
-        auto back = [&](uint32_t records) { return max(off, off_first + records * 64u) - records * 64u; };   // (the first record again past the front)
+        // (the first record again past the front; positions are relative to the list's first record, and the subtraction
+        // that stops at zero is written for the scalar unit: as an expression it becomes a vector instruction)
+        auto back = [&](uint32_t records) { return scalar_sub_floor0(off, records * 64u); };
         Rec C, D;
         rec_request(stream_rec, back(1u), B);
         for (uint32_t i = n >> 2; i != 0; --i) {
@@ -748,7 +764,7 @@ __device__ inline void bwd_sweep(const WaveGeom &w, const float *__restrict__ st
         entry(A, k);
         if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
         rec_wait(B);
-        rec_request(stream_rec, max(off, off_first + 128u) - 128u, A);   // (the first record again after the last pair)
+        rec_request(stream_rec, scalar_sub_floor0(off, 128u), A);   // (the first record again after the last pair)
         entry(B, k - 1u);
         if (MODE == kTileGroup && ++gs.entry == kGroupChunk) group_flush(gs, kGroupChunk, pairgrad);
         off -= 128u;
@@ -782,6 +798,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     WaveGeom w;
     if (!wave_setup(v, tile_offsets, tile_order, w)) return;
     if (w.begin >= w.end) return;   // (the same for every wave of a tile group)
+    stream_rec = list_start(stream_rec, w);
+    // per-block streams: a record names its row by its position in the block's own stream
+    if (MODE == kBlockRuns) pairgrad += (size_t)w.first * GSR_PAIRGRAD_FLOATS;
     raise_wave_priority(w, v.T);
     GroupSlot gs = {nullptr, nullptr, 0u, 1u, 0u, 0u, 0u, 1u};
     if (MODE == kTileGroup) {
@@ -953,7 +972,7 @@ extern "C" int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile
 static int blocks_view(const gsr_view *view_host, uint32_t num_pairs, ViewK *v, const char *who)
 {
     if (!view_host || !gsr_block_lists_supported(view_host, num_pairs)) {
-        gsr_set_error("%s: the view has no per-block lists (tile edges 32, 48, 64; pairs x blocks per tile < 2^26)", who);
+        gsr_set_error("%s: the view has no per-block lists (tile edges 32, 48, 64; pairs x blocks per tile < 2^28)", who);
         return GSR_ERR_ARG;
     }
     gsr_view v16 = *view_host;

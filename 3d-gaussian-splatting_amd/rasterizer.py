@@ -381,7 +381,7 @@ def _block_lists_of(st: RenderState) -> RenderState:
     i32 = dict(dtype=torch.int32, device=dev)
     offsets = torch.empty(T16 + 1, **i32)
     block_stream = torch.empty(I * S2, _lib.STREAM_DWORDS, dtype=torch.float32, device=dev)   # (the upper bound)
-    combo = torch.empty(I * S2, **i32)
+    combo = torch.empty(I * S2, dtype=torch.int64 if int(lib.gsr_block_combo_bytes(cv, I)) == 8 else torch.int32, device=dev)
     ws_bytes = int(lib.gsr_block_lists_workspace_bytes(cv, I))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _call("gsr_block_lists", lib.gsr_block_lists, cv, _ptr(st.tile_offsets), _ptr(st.stream_rec), I, _ptr(offsets), _ptr(block_stream),

@@ -309,13 +309,15 @@ int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, c
  * record layout of one-block tiles, and the kernels of one-block tiles composite these streams.  Results agree with
  * gsr_composite_fwd / gsr_composite_bwd to rounding (the product 0.99^n is formed in another order); the gradients
  * are reproducible run to run.
- *   gsr_block_lists_supported   1 for tile_length 32 / 48 / 64 with num_pairs x blocks-per-tile < 2^26 - 1, else 0
+ *   gsr_block_lists_supported   1 for tile_length 32 / 48 / 64 with num_pairs x blocks-per-tile < 2^28, else 0
+ *   gsr_block_combo_bytes       bytes per word of combo: 4, or 8 from 2^26 - 1 pair-block combinations on
  *   gsr_block_count             T16 = ceil(width / 16) * ceil(height / 16); block id = Y16 + ceil(height / 16) * X16
  *   gsr_block_lists             from tile_offsets and stream_rec of gsr_bin_lists: block_offsets[T16 + 1],
  *                               block_stream[R, 16] (R <= num_pairs x S^2 records, S = tile_length / 16: allocate that;
- *                               every record carries its own index r), combo[num_pairs x S^2] (per list position and
- *                               block: 0xFFFFFFFF outside the image, r << 6 | 32 evaluated by record r, r << 6 | index
- *                               inside run r).  gsr_tile_order with tile_length = 16 orders the blocks.
+ *                               every record carries its index in its block's stream), combo[num_pairs x S^2] words
+ *                               of gsr_block_combo_bytes (per list position and block: all ones outside the image,
+ *                               r << 6 | 32 evaluated by record r, r << 6 | index inside run r).  gsr_tile_order with
+ *                               tile_length = 16 orders the blocks.  The streams may exceed 4 GiB.
  *   gsr_composite_blocks_fwd    img, final_T as gsr_composite_fwd
  *   gsr_composite_blocks_bwd    block_grad[R, 12] (allocate num_pairs x S^2 rows): row r belongs to stream record r -
  *                               the gradient record of an evaluated entry, or, for a run, the six sums over the block
@@ -324,17 +326,18 @@ int gsr_composite_bwd(const gsr_view *view_host, const uint32_t *tile_offsets, c
  *                               blocks in a fixed order, plus 0.01 x 0.99^i x run sum for the blocks on which the entry
  *                               was inside a run): what gsr_pair_reduce takes with parts = 1 */
 int gsr_block_lists_supported(const gsr_view *view_host, uint32_t num_pairs);
+uint32_t gsr_block_combo_bytes(const gsr_view *view_host, uint32_t num_pairs);
 uint32_t gsr_block_count(const gsr_view *view_host);
 size_t gsr_block_lists_workspace_bytes(const gsr_view *view_host, uint32_t num_pairs);
 int gsr_block_lists(const gsr_view *view_host, const uint32_t *tile_offsets, const float *stream_rec, uint32_t num_pairs,
-                    uint32_t *block_offsets, float *block_stream, uint32_t *combo, void *workspace, size_t workspace_bytes,
+                    uint32_t *block_offsets, float *block_stream, void *combo, void *workspace, size_t workspace_bytes,
                     void *stream);
 int gsr_composite_blocks_fwd(const gsr_view *view_host, uint32_t num_pairs, const uint32_t *block_offsets,
                              const uint32_t *block_order, const float *block_stream, float *img, float *final_T, void *stream);
 int gsr_composite_blocks_bwd(const gsr_view *view_host, uint32_t num_pairs, const uint32_t *block_offsets,
                              const uint32_t *block_order, const float *block_stream, const float *final_T, const float *dimg,
                              float *block_grad, void *stream);
-int gsr_block_rows_reduce(const gsr_view *view_host, uint32_t num_pairs, const float *stream_rec, const uint32_t *combo,
+int gsr_block_rows_reduce(const gsr_view *view_host, uint32_t num_pairs, const float *stream_rec, const void *combo,
                           const float *block_grad, float *pairgrad, void *stream);
 
 /* ---- training loss of one view ----------------------------------------------------------

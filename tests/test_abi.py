@@ -92,9 +92,11 @@ def test_block_list_queries_do_not_need_a_gpu():
 
     for tile, want in ((16, 0), (32, 1), (40, 0), (48, 1), (64, 1), (80, 0), (128, 0)):
         assert lib.gsr_block_lists_supported(view(tile), 100_000) == want
-    assert lib.gsr_block_lists_supported(view(64), (1 << 22) - 1) == 1       # pairs x 16 blocks must stay below 2^26 - 1
-    assert lib.gsr_block_lists_supported(view(64), 1 << 22) == 0
-    assert lib.gsr_block_lists_supported(view(32), (1 << 24) - 1) == 1
+    assert lib.gsr_block_lists_supported(view(64), (1 << 24) - 1) == 1       # pairs x 16 blocks must stay below 2^28
+    assert lib.gsr_block_lists_supported(view(64), 1 << 24) == 0
+    assert lib.gsr_block_lists_supported(view(32), (1 << 26) - 1) == 1
+    # 32-bit combination words below 2^26 - 1 pair-block combinations, 64-bit ones from there on
+    assert lib.gsr_block_combo_bytes(view(64), (1 << 22) - 1) == 4 and lib.gsr_block_combo_bytes(view(64), 1 << 22) == 8
     assert lib.gsr_block_count(view(64)) == 120 * 68
     tiles = 30 * 17
     assert lib.gsr_block_lists_workspace_bytes(view(64), 1_000_000) >= 4 * (16 * (1_000_000 // 64 + tiles) + tiles + 120 * 68)

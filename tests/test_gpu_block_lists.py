@@ -22,13 +22,14 @@ OUTSIDE, EVALUATED_BIT = 0xFFFFFFFF, 32
 
 
 @pytest.fixture(autouse=True)
-def _restore_switch():
-    old = os.environ.get("GSR_BLOCK_LISTS")
+def _restore_switches():
+    old = {k: os.environ.get(k) for k in ("GSR_BLOCK_LISTS", "GSR_BLOCK_WIDE")}
     yield
-    if old is None:
-        os.environ.pop("GSR_BLOCK_LISTS", None)
-    else:
-        os.environ["GSR_BLOCK_LISTS"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def _render(p, view, cot, blocks):
@@ -50,8 +51,13 @@ def _scene(kind, n, W, H, deg, seed):
                                                  ("adv", 30000, 330, 210, 2, 32), ("syn", 200000, 800, 800, 3, 64),
                                                  ("syn", 5, 64, 48, 0, 64), ("syn", 3000, 17, 130, 1, 32),
                                                  ("opaque", 6000, 200, 160, 1, 64), ("opaque", 6000, 200, 160, 1, 32)])
-def test_block_lists_equal_the_tile_groups(kind, n, W, H, deg, tile):
+@pytest.mark.parametrize("wide", [False, True])
+def test_block_lists_equal_the_tile_groups(kind, n, W, H, deg, tile, wide):
+    """(``wide``: the 64-bit combination words that views with 2^26 - 1 or more pair-block combinations get)"""
     from gsplat_amd.rasterizer import ViewSpec
+    if wide and n > 50000:
+        pytest.skip("the wide words are exercised on the smaller scenes")
+    os.environ["GSR_BLOCK_WIDE"] = "1" if wide else "0"
     dev = torch.device("cuda:0")
     sc = _scene(kind, n, W, H, deg, 5)
     if kind == "opaque":            # opaque splats of some size on top of each other
@@ -63,10 +69,13 @@ def test_block_lists_equal_the_tile_groups(kind, n, W, H, deg, tile):
     a, ga = _render(p, view, cot, blocks=False)
     b, gb = _render(p, view, cot, blocks=True)
     assert a.blocks is None and b.blocks is not None
+    assert b.blocks.combo.dtype == (torch.int64 if wide else torch.int32)
     if kind == "opaque":
         # pixels whose transmittance underflows: their waves take the checked sweep of the backward, through runs too
-        combo = b.blocks.combo.cpu().numpy().view(np.uint32)
-        assert bool((b.final_T < 1.1754944e-38).any()) and bool(((combo != OUTSIDE) & ((combo & EVALUATED_BIT) == 0)).any())
+        combo = b.blocks.combo.cpu().numpy()
+        combo = combo.view(np.uint64 if wide else np.uint32)
+        out = np.uint64(0xFFFFFFFFFFFFFFFF) if wide else np.uint32(OUTSIDE)
+        assert bool((b.final_T < 1.1754944e-38).any()) and bool(((combo != out) & ((combo & EVALUATED_BIT) == 0)).any())
     # forward: only the order of the roundings differs
     assert_close(b.img.cpu().numpy(), a.img.cpu().numpy(), "img", rtol=2e-5)
     assert_close(b.final_T.cpu().numpy(), a.final_T.cpu().numpy(), "final_T", rtol=2e-5)
@@ -77,7 +86,7 @@ def test_block_lists_equal_the_tile_groups(kind, n, W, H, deg, tile):
 @pytest.mark.parametrize("tile,W,H", [(64, 330, 210), (48, 330, 210), (32, 200, 120)])
 def test_block_streams_follow_the_hint_flags(tile, W, H):
     """Every (list position, block) combination is either evaluated - then the block's stream holds the entry's record,
-    in list order, with its own index - or inside a run of entries whose two hint bits for that block are set; a run
+    in list order, with its index in the block's stream - or inside a run of entries whose two hint bits for that block are set; a run
     record carries 0.99^n and the run's colour; blocks beyond the image's edge have no stream."""
     from gsplat_amd import rasterizer as R
     dev = torch.device("cuda:0")
@@ -137,7 +146,7 @@ def test_block_streams_follow_the_hint_flags(tile, W, H):
                 if x[0] == "e":
                     pos = x[1]
                     assert not is_run[r]
-                    assert (word9[r] & 0x3FFFFFFF) == r and (word9[r] >> 30) == ((flags[pos] >> (2 * c)) & 3)
+                    assert (word9[r] & 0x3FFFFFFF) == r - lo and (word9[r] >> 30) == ((flags[pos] >> (2 * c)) & 3)
                     assert col[pos - b] == ((r << 6) | EVALUATED_BIT)
                     assert np.array_equal(brec[r, :9].view(np.uint32), tile_rec[pos, :9].view(np.uint32))   # y x D' A' o B' r ca g
                     assert brec[r, 10] == tile_rec[pos, 10] and brec[r, 12] == tile_rec[pos, 12] and brec[r, 14] == tile_rec[pos, 14]
@@ -146,7 +155,7 @@ def test_block_streams_follow_the_hint_flags(tile, W, H):
                     assert brec[r, 15] == np.float32(0.01) * tile_rec[pos, 8]
                 else:
                     first, length = x[1], x[2]
-                    assert is_run[r] and (word9[r] & 0x3FFFFFFF) == r
+                    assert is_run[r] and (word9[r] & 0x3FFFFFFF) == r - lo
                     assert np.array_equal(col[first - b:first - b + length], (r << 6) | np.arange(length, dtype=np.uint32))
                     P = np.float32(np.float64(np.float32(0.99)) ** length)
                     assert brec[r, 4] == P and abs(brec[r, 5] * P - 1.0) < 1e-6
@@ -174,8 +183,8 @@ def test_views_that_keep_the_tile_groups():
     os.environ["GSR_BLOCK_LISTS"] = "0"
     st = R.forward_pipeline(*p, None, R.ViewSpec.from_camera(sc.camera(device=dev), 1, 64))
     assert st.blocks is None
-    assert not lib.gsr_block_lists_supported(st.cview, 1 << 22)        # 2^22 pairs x 16 blocks = 2^26: too many records
-    assert lib.gsr_block_lists_supported(st.cview, (1 << 22) - 1)
+    assert not lib.gsr_block_lists_supported(st.cview, 1 << 24)        # 2^24 pairs x 16 blocks = 2^28: too many records
+    assert lib.gsr_block_lists_supported(st.cview, (1 << 24) - 1)
 
 
 def test_minibatch_at_the_default_tile_edge_equals_the_one_view_calls():
@@ -207,3 +216,29 @@ def test_minibatch_at_the_default_tile_edge_equals_the_one_view_calls():
         acc = [g.clone() for g in six[:5]] if acc is None else [a + g for a, g in zip(acc, six[:5])]
     for name, a, g in zip(GRADS, acc, grads):
         assert_close(g.cpu().numpy(), a.cpu().numpy(), name, rtol=2e-5)
+
+
+def test_block_streams_beyond_4_gib():
+    """Splats that cover the whole image: every block evaluates every entry of its tile, the block streams hold as many
+    records as there are pair-block combinations - more than 2^26 of them, more than 4 GiB, with 64-bit combination words -
+    and the compositing kernels address them from each list's own first record."""
+    from gsplat_amd import rasterizer as R
+    dev = torch.device("cuda:0")
+    W, H, n = 1920, 1080, 12000
+    sc = _scene("syn", n, W, H, 0, 11)
+    sc.scale = sc.scale + 8.0
+    p = [t.to(dev) for t in sc.params()]
+    view = R.ViewSpec.from_camera(sc.camera(device=dev), 0, 64)
+    cot = torch.rand(W, H, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    b, gb = _render(p, view, cot, blocks=True)
+    assert b.blocks is not None and b.blocks.combo.dtype == torch.int64
+    records = int(b.blocks.offsets[-1].item())
+    assert b.num_pairs * 16 >= (1 << 26) and records * 64 > (1 << 32), (b.num_pairs, records)
+    img, final_T = b.img.clone(), b.final_T.clone()
+    del b
+    torch.cuda.empty_cache()
+    a, ga = _render(p, view, cot, blocks=False)
+    assert_close(img.cpu().numpy(), a.img.cpu().numpy(), "img", rtol=2e-5)
+    assert_close(final_T.cpu().numpy(), a.final_T.cpu().numpy(), "final_T", rtol=2e-5)
+    for name, x, y in zip(GRADS, gb, ga):
+        assert_close(x.cpu().numpy(), y.cpu().numpy(), name, **grad_tolerance(n))
