@@ -841,6 +841,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         float Tf[4], Ts[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Tf[j] = 1.0f; Ts[j] = 0.0f; nstop[j] = len; }
+        bool inside[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) inside[j] = w.vx && (w.y0 + 4 * j) < w.ylim;
+        // some pixel of the wave (inside the image) has not reached its stop yet
+        auto wave_live = [&]() {
+            bool live = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) live |= inside[j] && nstop[j] == len;
+            return __ballot(live) != 0ull;
+        };
+        bool all_stopped = false;
         auto forward_step = [&](const Rec &R, uint32_t idx) {
             const uint32_t bf = block_flags<!one_block_layout(MODE)>(rec_flags<one_block_layout(MODE)>(R.d), w.flag_shift);
             const bool low[2] = {(bf & kLowTop) != 0, (bf & kLowBottom) != 0};
@@ -881,15 +892,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 forward_step(B, idx + 1u);
                 off += 128u;
                 idx += 2u;
+                // (per-block streams, where a record's gradient row is its position: once every pixel has stopped, the rest
+                // of the list matters to none of them - see below)
+                if (MODE == kBlockRuns && (idx & 14u) == 0u && !wave_live()) { all_stopped = true; break; }
             }
             rec_wait(A);
             l2_touch_drain(sink);
-            if (len & 1u) forward_step(A, idx);
+            if ((len & 1u) && !all_stopped) forward_step(A, idx);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool inside = w.vx && (w.y0 + 4 * j) < w.ylim;
-            if (nstop[j] != len) T[j >> 1][j & 1] = inside ? Ts[j] : 0.0f;
+            if (nstop[j] != len) T[j >> 1][j & 1] = inside[j] ? Ts[j] : 0.0f;
+        }
+        if (MODE == kBlockRuns && !wave_live()) {
+            // Every pixel of the block dropped out before the list ended (at a tile edge of 64 with a few million
+            // Gaussians: two thirds into a list of 9000 entries): the records behind the last stop get zero rows without
+            // being read, and the sweep starts at that stop.
+            uint32_t last = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) last = inside[j] ? max(last, nstop[j]) : last;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) last = max(last, (uint32_t)__shfl_xor((int)last, d, 64));
+            last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
+            const int lane = threadIdx.x & 63;
+            if (lane < 63)   // three lanes per row, 21 rows per turn
+                for (uint32_t r = last + (uint32_t)(lane / 3); r < len; r += 21u)
+                    reinterpret_cast<float4 *>(pairgrad + (size_t)r * GSR_PAIRGRAD_FLOATS)[lane % 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (last == 0u) return;
+            WaveGeom head = w;
+            head.end = last;
+            bwd_sweep<true, MODE>(head, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, gs);
+            return;
         }
         bwd_sweep<true, MODE>(w, stream_rec, pxf, pyf, T, gr, gg, gb, nstop, pairgrad, gs);
     } else {
