@@ -892,9 +892,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 forward_step(B, idx + 1u);
                 off += 128u;
                 idx += 2u;
-                // (per-block streams, where a record's gradient row is its position: once every pixel has stopped, the rest
-                // of the list matters to none of them - see below)
-                if (MODE == kBlockRuns && (idx & 14u) == 0u && !wave_live()) { all_stopped = true; break; }
+                // (one wave per list: once every pixel has stopped, the rest of the list matters to none of them - see below)
+                if (one_block_layout(MODE) && (idx & 14u) == 0u && !wave_live()) { all_stopped = true; break; }
             }
             rec_wait(A);
             l2_touch_drain(sink);
@@ -904,10 +903,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         for (int j = 0; j < 4; ++j) {
             if (nstop[j] != len) T[j >> 1][j & 1] = inside[j] ? Ts[j] : 0.0f;
         }
-        if (MODE == kBlockRuns && !wave_live()) {
+        if (one_block_layout(MODE) && !wave_live()) {
             // Every pixel of the block dropped out before the list ended (at a tile edge of 64 with a few million
             // Gaussians: two thirds into a list of 9000 entries): the records behind the last stop get zero rows without
-            // being read, and the sweep starts at that stop.
+            // being blended, and the sweep starts at that stop.
             uint32_t last = 0u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) last = inside[j] ? max(last, nstop[j]) : last;
@@ -915,9 +914,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             for (int d = 32; d >= 1; d >>= 1) last = max(last, (uint32_t)__shfl_xor((int)last, d, 64));
             last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
             const int lane = threadIdx.x & 63;
-            if (lane < 63)   // three lanes per row, 21 rows per turn
-                for (uint32_t r = last + (uint32_t)(lane / 3); r < len; r += 21u)
-                    reinterpret_cast<float4 *>(pairgrad + (size_t)r * GSR_PAIRGRAD_FLOATS)[lane % 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == kBlockRuns) {
+                // (a record's row is its position in the stream: three lanes per row, 21 rows per turn)
+                if (lane < 63)
+                    for (uint32_t r = last + (uint32_t)(lane / 3); r < len; r += 21u)
+                        reinterpret_cast<float4 *>(pairgrad + (size_t)r * GSR_PAIRGRAD_FLOATS)[lane % 3] = zero;
+            } else {
+                // (a record's row is named by its slot field: a lane per record)
+                for (uint32_t r = last + (uint32_t)lane; r < len; r += 64u) {
+                    const uint32_t slot = __float_as_uint(stream_rec[(size_t)r * GSR_STREAM_DWORDS + 9]) & ((1u << kSlotBits) - 1u);
+                    float4 *dst = reinterpret_cast<float4 *>(pairgrad + (size_t)slot * GSR_PAIRGRAD_FLOATS);
+                    dst[0] = zero; dst[1] = zero; dst[2] = zero;
+                }
+            }
             if (last == 0u) return;
             WaveGeom head = w;
             head.end = last;
