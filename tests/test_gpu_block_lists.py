@@ -14,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from util import assert_close, grad_tolerance  # noqa: E402
+from util import assert_close, assert_close_nan, grad_tolerance, load_golden, nan_colour_golden_names, nonfinite_golden_names  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GRADS = ("g_coords", "g_scale", "g_rotation", "g_opacity", "g_sh", "g_screen")
@@ -242,3 +242,27 @@ def test_block_streams_beyond_4_gib():
     assert_close(final_T.cpu().numpy(), a.final_T.cpu().numpy(), "final_T", rtol=2e-5)
     for name, x, y in zip(GRADS, gb, ga):
         assert_close(x.cpu().numpy(), y.cpu().numpy(), name, **grad_tolerance(n))
+
+
+@pytest.mark.parametrize("tile", [32, 64])
+def test_nan_and_infinite_inputs_spread_as_with_the_tile_groups(tile):
+    """The inputs of the fixtures with a NaN sh coefficient, a NaN opacity, NaN / infinite coordinates and degenerate
+    quaternions (generated from the reference at a tile edge of 16), rendered at tile edges of several blocks: the
+    per-block lists turn the same pixels and the same gradient entries NaN as the tile groups, the rest agrees."""
+    from gsplat_amd import rasterizer as R
+    dev = torch.device("cuda:0")
+    names = nan_colour_golden_names() + nonfinite_golden_names()
+    assert names
+    for name in names:
+        g = load_golden(name)
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)  # noqa: E731
+        p = [t(g["coords"]), t(g["scale"]), t(g["rotation"]), t(np.asarray(g["opacity"]).reshape(-1, 1)), t(g["sh"])]
+        f = lambda a, k: tuple(np.asarray(a, np.float32).reshape(k).tolist())  # noqa: E731
+        view = R.ViewSpec(int(g["sh_degree"]), int(g["width"]), int(g["height"]), tile, f(g["w2m"], 16), f(g["proj"], 16), f(g["cam_pos"], 3))
+        cot = t(g["cotangent"])
+        a, ga = _render(p, view, cot, blocks=False)
+        b, gb = _render(p, view, cot, blocks=True)
+        assert a.blocks is None and b.blocks is not None
+        assert_close_nan(b.img.cpu().numpy(), a.img.cpu().numpy(), name + " img", rtol=2e-5)
+        for key, x, y in zip(GRADS, gb, ga):
+            assert_close_nan(x.cpu().numpy(), y.cpu().numpy(), name + " " + key, **grad_tolerance(len(g["coords"])))
