@@ -331,7 +331,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_measured_at_pairs": traffic_pairs,
                 "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": round(dom_ms, 4),
                 "avg_launch_ms_alone": None if dom_alone_ms is None else round(dom_alone_ms, 4),
-                "note": "compositing is bound by vector instruction issue at these list lengths (SQ counters: profiles/r02t_pmc_composite_sq.txt), not by HBM; "
+                "note": "compositing is bound by vector instruction issue at these list lengths (SQ counters: profiles/r04d_pmc_composite_sq.txt), not by HBM; "
                         "traffic = HBM-side bytes of one launch of this kernel on this workload's first view from the PMC passes under profiles/ (traffic.json); avg_launch_ms is measured in "
                         "the timed region, where the next view's pair emission, tile sort and record stream run beside the kernel on a second "
                         "stream and share the CUs with it (avg_launch_ms_alone: the same launch with nothing beside it); "
